@@ -1,0 +1,265 @@
+"""Host-side Python mirror of the MI355X EMS NB-LDPC decoder library (libems_hip.so).
+
+This package is plumbing over the C ABI of ``include/ems_abi.h`` / ``include/nbldpc_ref_api.h``: it
+loads the shared library with ctypes and exposes the reference's operator names (``LoadCode``,
+``LoadTables``, ``ModelChannel_AWGN_BPSK``, ``Decoding``, ``CheckPassLogEMS``, ``ElementaryStep``,
+``Decision``, ``Syndrom``) plus the batched ``Decoder`` the GPU path really uses.  All compute runs in
+the hand-written HIP kernels; nothing here (or in the library) falls back to the CPU, and nothing here
+imports ``oracle/``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libems_hip.so")
+SIM_PATH = os.path.join(PKG_DIR, "ems_sim")
+
+EMS_OK, EMS_EINVAL, EMS_ENODEV, EMS_EHIP, EMS_EIO, EMS_ENOMEM, EMS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+
+class EmsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ems error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP kernels + C ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", CSRC]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+class CodeDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("M", C.c_int), ("GF", C.c_int), ("logGF", C.c_int), ("nbBranch", C.c_int),
+                ("rowDegree", C.POINTER(C.c_int)), ("col", C.POINTER(C.c_int)), ("coef", C.POINTER(C.c_int))]
+
+
+class Params(C.Structure):
+    _fields_ = [("nm", C.c_int), ("nbOper", C.c_int), ("offset", C.c_float), ("NbIterMax", C.c_int),
+                ("early_exit", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libems_hip.so.  Raises if it has not been built: there is no Python/CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EmsError(EMS_ENODEV, "libems_hip.so is not built (run build() / make -C csrc); no fallback exists")
+        L = C.CDLL(LIB_PATH)
+        L.ems_last_error.restype = C.c_char_p
+        L.ems_version.restype = C.c_char_p
+        L.ems_last_llr_ms.restype = C.c_float
+        L.ems_last_decode_ms.restype = C.c_float
+        L.ems_last_llr_ms.argtypes = [C.c_void_p]
+        L.ems_last_decode_ms.argtypes = [C.c_void_p]
+        L.ems_noisy_dev_ptr.restype = C.c_void_p
+        L.ems_noisy_dev_ptr.argtypes = [C.c_void_p]
+        L.ems_stream.restype = C.c_void_p
+        L.ems_stream.argtypes = [C.c_void_p]
+        L.ems_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CodeDesc), C.POINTER(Params), C.c_int, C.c_int]
+        L.ems_destroy.argtypes = [C.c_void_p]
+        L.ems_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.ems_llr_init.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+        L.ems_llr_init_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+        L.ems_load_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ems_decode.argtypes = [C.c_void_p, C.c_int]
+        L.ems_get_results.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ems_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ems_count_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ems_get_app.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ems_get_ctov.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ems_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.ems_synchronize.argtypes = [C.c_void_p]
+        L.ems_load_code_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(CodeDesc)]
+        L.ems_free_code_desc.argtypes = [C.POINTER(CodeDesc)]
+        L.ems_gf_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.ems_elementary_step.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
+        L.ems_check_node.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_int]
+        L.ems_decision.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ems_syndrome.argtypes = [C.POINTER(CodeDesc), C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise EmsError(rc, lib().ems_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Code:
+    """A parity-check matrix as ``LoadCode`` (init.c:143) reads it; both on-disk layouts are accepted."""
+
+    def __init__(self, path, fmt=0):
+        self.desc = CodeDesc()
+        _check(lib().ems_load_code_file(os.fsencode(path), fmt, C.byref(self.desc)))
+        d = self.desc
+        self.N, self.M, self.K, self.GF, self.logGF, self.E = d.N, d.M, d.N - d.M, d.GF, d.logGF, d.nbBranch
+        self.rate = np.float32(self.K) / np.float32(self.N)          # (float)(N-M)/N, init.c:170
+        self.rowDegree = np.ctypeslib.as_array(d.rowDegree, (self.M,))
+        self.col = np.ctypeslib.as_array(d.col, (self.E,))
+        self.coef = np.ctypeslib.as_array(d.coef, (self.E,))
+        self.dc = int(self.rowDegree[0])
+
+    def __del__(self):
+        try:
+            lib().ems_free_code_desc(C.byref(self.desc))
+        except Exception:
+            pass
+
+
+def gf_tables(q):
+    """(idx2bin, bin2idx) as LoadTables (init.c:427) derives them from struct.h's binary images."""
+    a = np.zeros(q, np.uint8)
+    b = np.zeros(q, np.uint8)
+    _check(lib().ems_gf_tables(q, _ptr(a), _ptr(b)))
+    return a, b
+
+
+class Decoder:
+    """Batched EMS decoder for one code on one GPU (``ems_create`` ... ``ems_destroy``)."""
+
+    def __init__(self, code, nm, nbOper, offset, NbIterMax, max_batch, device=0, early_exit=True):
+        self.code = code
+        self.max_batch = max_batch
+        self.prm = Params(nm, nbOper, offset, NbIterMax, int(bool(early_exit)))
+        self.h = C.c_void_p()
+        _check(lib().ems_create(C.byref(self.h), C.byref(code.desc), C.byref(self.prm), max_batch, device))
+
+    def close(self):
+        if self.h:
+            lib().ems_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            setattr(self.prm, k, v)
+        _check(lib().ems_set_params(self.h, C.byref(self.prm)))
+
+    # ---- hot path ----
+    def llr_init(self, noisy, sigma):
+        noisy = np.ascontiguousarray(noisy, np.float32)
+        B = noisy.shape[0]
+        assert noisy.shape == (B, self.code.N, self.code.logGF)
+        _check(lib().ems_llr_init(self.h, _ptr(noisy), np.float32(sigma), B))
+        return B
+
+    def llr_init_dev(self, dev_ptr, sigma, B):
+        _check(lib().ems_llr_init_dev(self.h, C.c_void_p(dev_ptr), np.float32(sigma), B))
+
+    def load_llr(self, llr):
+        llr = np.ascontiguousarray(llr, np.float32)
+        B = llr.shape[0]
+        assert llr.shape == (B, self.code.N, self.code.GF)
+        _check(lib().ems_load_llr(self.h, _ptr(llr), B))
+        return B
+
+    def decode(self, B):
+        _check(lib().ems_decode(self.h, B))
+
+    def results(self, B):
+        decide = np.zeros((B, self.code.N), np.int32)
+        iters = np.zeros(B, np.int32)
+        synd = np.zeros(B, np.int32)
+        _check(lib().ems_get_results(self.h, B, _ptr(decide), _ptr(iters), _ptr(synd)))
+        return decide, iters, synd
+
+    def decode_batch(self, noisy, sigma):
+        B = self.llr_init(noisy, sigma)
+        self.decode(B)
+        return self.results(B)
+
+    def count_errors(self, codewords):
+        cw = np.ascontiguousarray(codewords, np.int32)
+        B = cw.shape[0]
+        out = np.zeros(B, np.int32)
+        _check(lib().ems_count_errors(self.h, _ptr(cw), B, _ptr(out)))
+        return out
+
+    # ---- introspection ----
+    def app(self, frame):
+        a = np.zeros((self.code.N, self.code.GF), np.float32)
+        _check(lib().ems_get_app(self.h, frame, _ptr(a)))
+        return a
+
+    def ctov(self, frame):
+        a = np.zeros((self.code.E, self.code.GF), np.float32)
+        _check(lib().ems_get_ctov(self.h, frame, _ptr(a)))
+        return a
+
+    def schedule(self):
+        nl = C.c_int(0)
+        lp = np.zeros(self.code.M + 1, np.int32)
+        order = np.zeros(self.code.M, np.int32)
+        _check(lib().ems_get_schedule(self.h, C.byref(nl), _ptr(lp), _ptr(order)))
+        return lp[: nl.value + 1].copy(), order
+
+    def synchronize(self):
+        _check(lib().ems_synchronize(self.h))
+
+    @property
+    def last_decode_ms(self):
+        return float(lib().ems_last_decode_ms(self.h))
+
+    @property
+    def last_llr_ms(self):
+        return float(lib().ems_last_llr_ms(self.h))
+
+    @property
+    def noisy_dev_ptr(self):
+        return lib().ems_noisy_dev_ptr(self.h)
+
+
+# ---- single-node operators on the device (bubble_decoder.c / tools.c shapes) ----
+def ElementaryStep(Input1, Input2, IndiceInput1, IndiceInput2, GF, nbMax, nbOper, device=0):
+    """bubble_decoder.c:316 -- returns (Output, IndiceOut)."""
+    a = np.ascontiguousarray(Input1, np.float32); b = np.ascontiguousarray(Input2, np.float32)
+    ia = np.ascontiguousarray(IndiceInput1, np.int32); ib = np.ascontiguousarray(IndiceInput2, np.int32)
+    out = np.zeros(nbMax, np.float32); io = np.zeros(nbMax, np.int32)
+    _check(lib().ems_elementary_step(GF, nbMax, nbOper, _ptr(a), _ptr(b), _ptr(ia), _ptr(ib), _ptr(out), _ptr(io), device))
+    return out, io
+
+
+def CheckPassLogEMS(coef, M_VtoC_LLR, M_VtoC_GF, GF, NbOper, offset, device=0):
+    """bubble_decoder.c:72 -- inputs [dc][nm] (sorted, normalised, unrotated); returns M_CtoV_LLR [dc][GF]."""
+    coef = np.ascontiguousarray(coef, np.int32)
+    vl = np.ascontiguousarray(M_VtoC_LLR, np.float32); vg = np.ascontiguousarray(M_VtoC_GF, np.int32)
+    dc, nm = vl.shape
+    out = np.zeros((dc, GF), np.float32)
+    _check(lib().ems_check_node(GF, dc, nm, NbOper, np.float32(offset), _ptr(coef), _ptr(vl), _ptr(vg), _ptr(out), device))
+    return out
+
+
+def Decision(APP, device=0):
+    """tools.c:312"""
+    app = np.ascontiguousarray(APP, np.float32)
+    d = np.zeros(app.shape[0], np.int32)
+    _check(lib().ems_decision(app.shape[1], app.shape[0], _ptr(app), _ptr(d), device))
+    return d
+
+
+def Syndrom(code, decide, device=0):
+    """tools.c:284"""
+    d = np.ascontiguousarray(decide, np.int32)
+    s = C.c_int(0)
+    _check(lib().ems_syndrome(C.byref(code.desc), _ptr(d), C.byref(s), device))
+    return s.value

@@ -1,0 +1,630 @@
+// ems_core.cpp -- host side of libems_hip.so: alist loader, GF(q) tables, layered level schedule,
+// device state and the batched C ABI declared in include/ems_abi.h.  Compiled with hipcc.
+//
+// There is deliberately no CPU implementation of the decode path in this library: every compute entry
+// point launches the gfx950 kernels of ems_kernels.hip and reports EMS_ENODEV / EMS_EHIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/ems_abi.h"
+#include "ems_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(EMS_EHIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+int select_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(EMS_ENODEV, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(EMS_ENODEV, "HIP device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return EMS_OK;
+}
+
+// ---- GF(q): primitive polynomials of struct.h:117 / :145 / :217 ----
+int gf_build(int q, uint8_t *i2b, uint8_t *b2i)
+{
+    unsigned poly;
+    if (q == 16) poly = 0x13;
+    else if (q == 64) poly = 0x43;
+    else if (q == 256) poly = 0x11D;
+    else return fail(EMS_EUNSUPPORTED, "GF(%d): only GF(16), GF(64), GF(256) are available (init.c:431)", q);
+    unsigned b = 1;
+    i2b[0] = 0;
+    b2i[0] = 0;
+    for (int i = 1; i < q; ++i) {
+        i2b[i] = (uint8_t)b;
+        b2i[b] = (uint8_t)i;
+        b <<= 1;
+        if (b & (unsigned)q) b ^= poly;
+    }
+    return EMS_OK;
+}
+
+int ilog2(int q)
+{
+    int l = 0;
+    while ((1 << l) < q) ++l;
+    return l;
+}
+
+// forward/backward/merge task table (see cn_core in ems_kernels.hip)
+struct CnSchedule {
+    int nsteps = 0, n_lists = 0;
+    std::vector<int8_t> tasks; // [nsteps][4][3]
+    int8_t out_list[16];
+};
+
+int build_cn_schedule(int dc, CnSchedule &s)
+{
+    if (dc < 2 || dc > 16) return fail(EMS_EUNSUPPORTED, "check-node degree %d not supported", dc);
+    auto in = [&](int i) { return i; };
+    auto Pl = [&](int k) { return k == 0 ? in(0) : dc + (k - 1); };
+    auto Sl = [&](int k) { return k == dc - 1 ? in(dc - 1) : dc + (dc - 2) + (k - 1); };
+    auto Ml = [&](int k) { return dc + 2 * (dc - 2) + k; };
+    s.nsteps = dc - 2;
+    s.n_lists = dc + 3 * (dc - 2);
+    s.tasks.assign((size_t)std::max(s.nsteps, 1) * 12, (int8_t)-1);
+    for (int t = 1; t <= dc - 2; ++t) {
+        int8_t *row = &s.tasks[(size_t)(t - 1) * 12];
+        int slot = 0;
+        auto put = [&](int a, int b, int o) {
+            row[slot * 3 + 0] = (int8_t)a;
+            row[slot * 3 + 1] = (int8_t)b;
+            row[slot * 3 + 2] = (int8_t)o;
+            ++slot;
+        };
+        put(Pl(t - 1), in(t), Pl(t));                     // bubble_decoder.c:192 forward
+        put(Sl(dc - t), in(dc - 1 - t), Sl(dc - 1 - t));  // bubble_decoder.c:198 backward
+        for (int k = 0; k <= dc - 3; ++k)                 // bubble_decoder.c:221 merges, as soon as ready
+            if (std::max(k, dc - 3 - k) + 1 == t) {
+                if (slot >= 4) return fail(EMS_EUNSUPPORTED, "internal: more than 4 tasks in a step");
+                put(Pl(k), Sl(k + 2), Ml(k));
+            }
+    }
+    memset(s.out_list, 0, sizeof s.out_list);
+    for (int t = 0; t < dc; ++t)
+        s.out_list[t] = (int8_t)(t == 0 ? Sl(1) : (t == dc - 1 ? Pl(dc - 2) : Ml(t - 1)));
+    return EMS_OK;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        n = count;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return fail(EMS_ENOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+        return EMS_OK;
+    }
+    int upload(const std::vector<T> &h)
+    {
+        int r = alloc(h.size());
+        if (r) return r;
+        if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return EMS_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+} // namespace
+
+struct ems_handle {
+    int device = 0, max_batch = 0, nm_alloc = 0;
+    int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
+    ems_params prm{};
+    std::vector<int> lvl_ptr, lvl_cn, cn_vn;
+    std::vector<uint8_t> cn_lh, i2b, b2i;
+    CnSchedule cs;
+    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr;
+    DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
+    DevBuf<int8_t> d_sched;
+    DevBuf<float> d_app, d_noisy, d_scratch;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_llr_ev = false, have_dec_ev = false;
+    EmsPlan plan{};
+};
+
+namespace {
+
+int refresh_plan(ems_handle *h)
+{
+    const ems_params &p = h->prm;
+    if (p.nm < 5 || p.nm > EMS_MAX_NM || p.nm > h->nm_alloc || p.nm > h->q)
+        return fail(EMS_EINVAL, "nm=%d outside [5, min(%d, GF)] or above the value given at create", p.nm, EMS_MAX_NM);
+    if (p.nbOper < 1 || p.NbIterMax < 2) return fail(EMS_EINVAL, "nbOper >= 1 and NbIterMax >= 2 required");
+    EmsPlan &P = h->plan;
+    P.N = h->N; P.M = h->M; P.E = h->E; P.q = h->q; P.logq = h->logq; P.dc = h->dc;
+    P.nm = p.nm; P.nbOper = p.nbOper; P.nsweeps = p.NbIterMax - 1; P.early_exit = p.early_exit ? 1 : 0;
+    P.offset = p.offset;
+    P.n_levels = (int)h->lvl_ptr.size() - 1;
+    P.lvl_ptr = h->d_lvl_ptr.p; P.lvl_cn = h->d_lvl_cn.p; P.cn_vn = h->d_cn_vn.p; P.cn_lh = h->d_cn_lh.p;
+    P.nsteps = h->cs.nsteps; P.sched = h->d_sched.p; P.n_lists = h->cs.n_lists;
+    memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
+    P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
+    P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
+    P.rec_bytes = ems_rec_bytes(h->nm_alloc);
+    P.wave_lds_bytes = (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
+    int widest = 1;
+    for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
+    int waves = std::min(16, widest);
+    const size_t lds_cap = 160 * 1024;
+    while (waves > 1 && ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) --waves;
+    if (ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
+    P.waves_per_wg = waves;
+    return EMS_OK;
+}
+
+} // namespace
+
+namespace {
+struct Tmp {
+    std::vector<void *> ptrs;
+    ~Tmp() { for (void *p : ptrs) (void)hipFree(p); }
+    template <typename T> T *up(const T *src, size_t n)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return (T *)p;
+    }
+};
+} // namespace
+
+extern "C" {
+
+const char *ems_last_error(void) { return g_err.c_str(); }
+const char *ems_version(void) { return "ems-hip 0.1 (gfx950)"; }
+
+int ems_gf_tables(int q, uint8_t *idx2bin, uint8_t *bin2idx)
+{
+    if (!idx2bin || !bin2idx) return fail(EMS_EINVAL, "null table pointer");
+    uint8_t a[256], b[256];
+    int r = gf_build(q, a, b);
+    if (r) return r;
+    memcpy(idx2bin, a, (size_t)q);
+    memcpy(bin2idx, b, (size_t)q);
+    return EMS_OK;
+}
+
+// init.c:143-272, both layouts.  The interleaved "KN" layout stores (column+1, exponent) pairs
+// (init.c:218-221); the block "UBS" layout stores all 0-based columns, then all coefficient indices
+// (init.c:195-207).  Auto-detection validates each reading against the declared column degrees.
+int ems_load_code_file(const char *path, int fmt, ems_code_desc *d)
+{
+    if (!path || !d) return fail(EMS_EINVAL, "null argument");
+    memset(d, 0, sizeof *d);
+    FILE *f = fopen(path, "r");
+    if (!f) return fail(EMS_EIO, "cannot open matrix file %s", path);
+    int N, M, q;
+    if (fscanf(f, "%d %d %d", &N, &M, &q) != 3 || N <= 0 || M <= 0 || M >= N) {
+        fclose(f);
+        return fail(EMS_EIO, "%s: bad header", path);
+    }
+    std::vector<int> cdeg(N), rdeg(M);
+    bool ok = true;
+    for (int n = 0; n < N && ok; ++n) ok = fscanf(f, "%d", &cdeg[n]) == 1;
+    for (int m = 0; m < M && ok; ++m) ok = fscanf(f, "%d", &rdeg[m]) == 1 && rdeg[m] > 0;
+    long E = 0;
+    for (int m = 0; m < M && ok; ++m) E += rdeg[m];
+    std::vector<int> tok;
+    if (ok) {
+        tok.resize((size_t)2 * E);
+        size_t nt = 0;
+        while (nt < tok.size() && fscanf(f, "%d", &tok[nt]) == 1) ++nt;
+        ok = nt == tok.size();
+    }
+    fclose(f);
+    if (!ok) return fail(EMS_EIO, "%s: truncated or malformed alist", path);
+
+    auto cols_ok = [&](auto colat) {
+        std::vector<int> cnt(N, 0);
+        for (long e = 0; e < E; ++e) {
+            int c = colat(e);
+            if (c < 0 || c >= N) return false;
+            ++cnt[c];
+        }
+        return cnt == cdeg;
+    };
+    bool ubs = cols_ok([&](long e) { return tok[e]; });
+    for (long e = 0; e < E && ubs; ++e) ubs = tok[E + e] >= 1 && tok[E + e] < q;
+    bool kn = cols_ok([&](long e) { return tok[2 * e] - 1; });
+    for (long e = 0; e < E && kn; ++e) kn = tok[2 * e + 1] >= 0 && tok[2 * e + 1] <= q - 2;
+    int use = fmt;
+    if (use == 0) use = ubs ? 1 : (kn ? 2 : -1);
+    if (use != 1 && use != 2) return fail(EMS_EIO, "%s: neither the UBS nor the KN alist layout validates", path);
+
+    int *rd = (int *)malloc(sizeof(int) * (size_t)M);
+    int *col = (int *)malloc(sizeof(int) * (size_t)E);
+    int *cf = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!rd || !col || !cf) { free(rd); free(col); free(cf); return fail(EMS_ENOMEM, "malloc"); }
+    memcpy(rd, rdeg.data(), sizeof(int) * (size_t)M);
+    for (long e = 0; e < E; ++e) {
+        col[e] = use == 1 ? tok[e] : tok[2 * e] - 1;
+        cf[e] = use == 1 ? tok[E + e] : tok[2 * e + 1] + 1;
+    }
+    d->N = N; d->M = M; d->GF = q; d->logGF = ilog2(q); d->nbBranch = (int)E;
+    d->rowDegree = rd; d->col = col; d->coef = cf;
+    return EMS_OK;
+}
+
+void ems_free_code_desc(ems_code_desc *d)
+{
+    if (!d) return;
+    free((void *)d->rowDegree);
+    free((void *)d->col);
+    free((void *)d->coef);
+    memset(d, 0, sizeof *d);
+}
+
+void ems_destroy(ems_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
+    h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
+    h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
+    h->d_scratch.release();
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, int max_batch, int device)
+{
+    if (!out || !c || !prm || max_batch < 1) return fail(EMS_EINVAL, "null argument or max_batch < 1");
+    *out = nullptr;
+    if (!c->rowDegree || !c->col || !c->coef || c->N <= 0 || c->M <= 0) return fail(EMS_EINVAL, "incomplete code description");
+    int r = select_device(device);
+    if (r) return r;
+
+    ems_handle *h = new ems_handle;
+    h->device = device; h->max_batch = max_batch; h->nm_alloc = prm->nm; h->prm = *prm;
+    h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
+    h->i2b.resize(256); h->b2i.resize(256);
+    auto bail = [&](int code) { ems_destroy(h); return code; };
+    if ((r = gf_build(h->q, h->i2b.data(), h->b2i.data()))) return bail(r);
+
+    // The kernels split a wave into dc equal edge rows, so the check degree must be constant (the
+    // reference sizes its per-CN scratch by rowDegree[0] and only warns otherwise, NB_LDPC.c:166-183).
+    h->dc = c->rowDegree[0];
+    long E = 0;
+    for (int m = 0; m < c->M; ++m) {
+        if (c->rowDegree[m] != h->dc) return bail(fail(EMS_EUNSUPPORTED, "irregular check degree (row %d has %d, row 0 has %d)", m, c->rowDegree[m], h->dc));
+        E += c->rowDegree[m];
+    }
+    if (E != c->nbBranch) return bail(fail(EMS_EINVAL, "nbBranch does not match the row degrees"));
+    if (!ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "check degree %d > 8 is not built", h->dc));
+    if (h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
+    if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
+
+    // Level schedule: level(c) = 1 + max level of the earlier check nodes that share a variable node.
+    // Visiting levels in order (any order inside a level) is the sequential order of NB_LDPC.c:320
+    // as far as every APP row is concerned; CtoV rows are private to their check node (:438).
+    h->cn_vn.assign(c->col, c->col + E);
+    h->cn_lh.resize(E);
+    std::vector<int> vn_level(h->N, -1), level(h->M, 0);
+    int nlev = 0;
+    for (int m = 0; m < h->M; ++m) {
+        int lv = 0;
+        for (int i = 0; i < h->dc; ++i) {
+            const int e = m * h->dc + i, v = c->col[e], cf = c->coef[e];
+            if (v < 0 || v >= h->N || cf < 1 || cf >= h->q) return bail(fail(EMS_EINVAL, "edge %d out of range", e));
+            for (int j = 0; j < i; ++j)
+                if (c->col[m * h->dc + j] == v) return bail(fail(EMS_EUNSUPPORTED, "check node %d lists variable node %d twice", m, v));
+            h->cn_lh[e] = (uint8_t)(cf - 1);
+            lv = std::max(lv, vn_level[v] + 1);
+        }
+        level[m] = lv;
+        for (int i = 0; i < h->dc; ++i) vn_level[c->col[m * h->dc + i]] = lv;
+        nlev = std::max(nlev, lv + 1);
+    }
+    h->lvl_ptr.assign(nlev + 1, 0);
+    for (int m = 0; m < h->M; ++m) ++h->lvl_ptr[level[m] + 1];
+    for (int l = 0; l < nlev; ++l) h->lvl_ptr[l + 1] += h->lvl_ptr[l];
+    h->lvl_cn.resize(h->M);
+    {
+        std::vector<int> fill(h->lvl_ptr.begin(), h->lvl_ptr.end() - 1);
+        for (int m = 0; m < h->M; ++m) h->lvl_cn[fill[level[m]]++] = m;
+    }
+
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(EMS_EHIP, "hipEventCreate failed"));
+    const size_t B = (size_t)max_batch;
+    if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
+        (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
+        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
+        (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
+        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)))
+        return bail(r);
+    if ((r = refresh_plan(h))) return bail(r);
+    *out = h;
+    return EMS_OK;
+}
+
+int ems_set_params(ems_handle *h, const ems_params *prm)
+{
+    if (!h || !prm) return fail(EMS_EINVAL, "null argument");
+    const ems_params old = h->prm;
+    h->prm = *prm;
+    int r = refresh_plan(h);
+    if (r) { h->prm = old; (void)refresh_plan(h); }
+    return r;
+}
+
+static int check_batch(ems_handle *h, int B)
+{
+    if (!h) return fail(EMS_EINVAL, "null handle");
+    if (B < 1 || B > h->max_batch) return fail(EMS_EINVAL, "batch %d outside [1, %d]", B, h->max_batch);
+    HIP_TRY(hipSetDevice(h->device));
+    return EMS_OK;
+}
+
+int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!noisy_dev) return fail(EMS_EINVAL, "null noisy pointer");
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(ems_launch_llr_init(noisy_dev, sigma, h->logq, h->q, (size_t)B * h->N * h->q, h->d_i2b.p, h->d_app.p, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_llr_ev = true;
+    return EMS_OK;
+}
+
+int ems_llr_init(ems_handle *h, const float *noisy_host, float sigma, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!noisy_host) return fail(EMS_EINVAL, "null noisy pointer");
+    HIP_TRY(hipMemcpyAsync(h->d_noisy.p, noisy_host, (size_t)B * h->N * h->logq * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    return ems_llr_init_dev(h, h->d_noisy.p, sigma, B);
+}
+
+int ems_load_llr(ems_handle *h, const float *llr_host, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!llr_host) return fail(EMS_EINVAL, "null llr pointer");
+    HIP_TRY(hipMemcpyAsync(h->d_app.p, llr_host, (size_t)B * h->N * h->q * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+int ems_decode(ems_handle *h, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(ems_launch_decode(h->plan, B, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    h->have_dec_ev = true;
+    return EMS_OK;
+}
+
+int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (decide) {
+        std::vector<uint8_t> tmp((size_t)B * h->N);
+        HIP_TRY(hipMemcpy(tmp.data(), h->d_decide.p, tmp.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) decide[i] = tmp[i];
+    }
+    if (iters) HIP_TRY(hipMemcpy(iters, h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+    if (synd) HIP_TRY(hipMemcpy(synd, h->d_synd.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
+
+int ems_decode_batch(ems_handle *h, const float *noisy_host, float sigma, int B, int *decide, int *iters, int *synd)
+{
+    int r = ems_llr_init(h, noisy_host, sigma, B);
+    if (r) return r;
+    if ((r = ems_decode(h, B))) return r;
+    return ems_get_results(h, B, decide, iters, synd);
+}
+
+int ems_count_errors(ems_handle *h, const int *cw_host, int B, int *nb_errors)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!cw_host || !nb_errors) return fail(EMS_EINVAL, "null argument");
+    HIP_TRY(hipMemcpyAsync(h->d_cw.p, cw_host, sizeof(int) * (size_t)B * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(ems_launch_count_errors(h->d_decide.p, h->d_cw.p, B, h->N, h->K, h->d_i2b.p, h->d_nberr.p, h->stream));
+    HIP_TRY(hipMemcpyAsync(nb_errors, h->d_nberr.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+int ems_get_app(ems_handle *h, int frame, float *app)
+{
+    int r = check_batch(h, frame + 1);
+    if (r) return r;
+    if (!app || frame < 0) return fail(EMS_EINVAL, "bad argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(app, h->d_app.p + (size_t)frame * h->N * h->q, sizeof(float) * (size_t)h->N * h->q, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
+
+int ems_get_ctov(ems_handle *h, int frame, float *ctov)
+{
+    int r = check_batch(h, frame + 1);
+    if (r) return r;
+    if (!ctov || frame < 0) return fail(EMS_EINVAL, "bad argument");
+    const size_t n = (size_t)h->E * h->q;
+    if (h->d_scratch.n < n) {
+        h->d_scratch.release();
+        if ((r = h->d_scratch.alloc(n))) return r;
+    }
+    const int rb = ems_rec_bytes(h->nm_alloc);
+    HIP_TRY(ems_launch_expand_ctov(h->d_ctov.p + (size_t)frame * h->E * rb, rb, h->nm_alloc, h->q, h->E, h->d_scratch.p, h->stream));
+    HIP_TRY(hipMemcpyAsync(ctov, h->d_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr, int *order)
+{
+    if (!h) return fail(EMS_EINVAL, "null handle");
+    if (n_levels) *n_levels = (int)h->lvl_ptr.size() - 1;
+    if (level_ptr) memcpy(level_ptr, h->lvl_ptr.data(), sizeof(int) * h->lvl_ptr.size());
+    if (order) memcpy(order, h->lvl_cn.data(), sizeof(int) * h->lvl_cn.size());
+    return EMS_OK;
+}
+
+float ems_last_llr_ms(const ems_handle *h)
+{
+    float ms = -1.f;
+    if (!h || !h->have_llr_ev) return ms;
+    if (hipEventSynchronize(h->ev[1]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+float ems_last_decode_ms(const ems_handle *h)
+{
+    float ms = -1.f;
+    if (!h || !h->have_dec_ev) return ms;
+    if (hipEventSynchronize(h->ev[3]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+void *ems_noisy_dev_ptr(ems_handle *h) { return h ? (void *)h->d_noisy.p : nullptr; }
+void *ems_stream(ems_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int ems_synchronize(ems_handle *h)
+{
+    if (!h) return fail(EMS_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// single-node entry points (device-backed; used by the reference-shaped symbols and the unit tests)
+// ---------------------------------------------------------------------------------------------------
+
+int ems_elementary_step(int GF, int nm, int nbOper, const float *in1, const float *in2, const int *idx1,
+                        const int *idx2, float *out, int *idxout, int device)
+{
+    if (!in1 || !in2 || !idx1 || !idx2 || !out || !idxout) return fail(EMS_EINVAL, "null argument");
+    if (nm < 5 || nm > EMS_MAX_NM || nbOper < 1) return fail(EMS_EINVAL, "nm outside [5,%d] or nbOper < 1", EMS_MAX_NM);
+    uint8_t i2b[256], b2i[256];
+    int r = gf_build(GF, i2b, b2i);
+    if (r || (r = select_device(device))) return r;
+    Tmp t;
+    float *d1 = t.up(in1, nm), *d2 = t.up(in2, nm), *dout = t.up<float>(nullptr, nm);
+    int *di1 = t.up(idx1, nm), *di2 = t.up(idx2, nm), *dio = t.up<int>(nullptr, nm);
+    uint8_t *da = t.up(i2b, 256), *db = t.up(b2i, 256);
+    if (!d1 || !d2 || !dout || !di1 || !di2 || !dio || !da || !db) return fail(EMS_ENOMEM, "device allocation failed");
+    HIP_TRY(ems_launch_es_unit(d1, d2, di1, di2, dout, dio, nm, nbOper, da, db, nullptr));
+    HIP_TRY(hipMemcpy(out, dout, sizeof(float) * nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(idxout, dio, sizeof(int) * nm, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
+
+int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *coef, const float *vtoc_llr,
+                   const int *vtoc_gf, float *ctov, int device)
+{
+    if (!coef || !vtoc_llr || !vtoc_gf || !ctov) return fail(EMS_EINVAL, "null argument");
+    if (nm < 5 || nm > EMS_MAX_NM || nbOper < 1) return fail(EMS_EINVAL, "nm outside [5,%d] or nbOper < 1", EMS_MAX_NM);
+    uint8_t i2b[256], b2i[256];
+    CnSchedule cs;
+    int r = gf_build(GF, i2b, b2i);
+    if (r || (r = build_cn_schedule(dc, cs)) || (r = select_device(device))) return r;
+    for (int t = 0; t < dc; ++t)
+        if (coef[t] < 1 || coef[t] >= GF) return fail(EMS_EINVAL, "coefficient %d out of range", coef[t]);
+    Tmp t;
+    int *dcoef = t.up(coef, dc), *dg = t.up(vtoc_gf, (size_t)dc * nm);
+    float *dl = t.up(vtoc_llr, (size_t)dc * nm), *dout = t.up<float>(nullptr, (size_t)dc * GF);
+    uint8_t *da = t.up(i2b, 256), *db = t.up(b2i, 256);
+    int8_t *ds = t.up(cs.tasks.data(), cs.tasks.size());
+    if (!dcoef || !dg || !dl || !dout || !da || !db || !ds) return fail(EMS_ENOMEM, "device allocation failed");
+    EmsPlan P{};
+    P.q = GF; P.dc = dc; P.nm = nm; P.nbOper = nbOper; P.offset = offset; P.nsteps = cs.nsteps; P.sched = ds;
+    P.n_lists = cs.n_lists; memcpy(P.out_list, cs.out_list, sizeof P.out_list);
+    P.idx2bin = da; P.bin2idx = db;
+    HIP_TRY(ems_launch_cn_unit(P, dcoef, dl, dg, dout, nullptr));
+    HIP_TRY(hipMemcpy(ctov, dout, sizeof(float) * (size_t)dc * GF, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
+
+int ems_decision(int GF, int N, const float *app, int *decide, int device)
+{
+    if (!app || !decide || N < 1 || GF < 2) return fail(EMS_EINVAL, "bad argument");
+    int r = select_device(device);
+    if (r) return r;
+    Tmp t;
+    float *da = t.up(app, (size_t)N * GF);
+    int *dd = t.up<int>(nullptr, N);
+    if (!da || !dd) return fail(EMS_ENOMEM, "device allocation failed");
+    HIP_TRY(ems_launch_decision_unit(da, N, GF, dd, nullptr));
+    HIP_TRY(hipMemcpy(decide, dd, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
+
+int ems_syndrome(const ems_code_desc *c, const int *decide, int *synd, int device)
+{
+    if (!c || !decide || !synd) return fail(EMS_EINVAL, "null argument");
+    uint8_t i2b[256], b2i[256];
+    int r = gf_build(c->GF, i2b, b2i);
+    if (r || (r = select_device(device))) return r;
+    std::vector<int> rp(c->M + 1, 0);
+    for (int m = 0; m < c->M; ++m) rp[m + 1] = rp[m] + c->rowDegree[m];
+    for (int n = 0; n < c->N; ++n)
+        if (decide[n] < 0 || decide[n] >= c->GF) return fail(EMS_EINVAL, "decision %d out of range", decide[n]);
+    Tmp t;
+    int *drp = t.up(rp.data(), rp.size()), *dcol = t.up(c->col, c->nbBranch), *dcf = t.up(c->coef, c->nbBranch);
+    int *dd = t.up(decide, c->N);
+    unsigned init = 0xFFFFFFFFu, *dfb = t.up(&init, 1);
+    uint8_t *da = t.up(i2b, 256), *db = t.up(b2i, 256);
+    if (!drp || !dcol || !dcf || !dd || !dfb || !da || !db) return fail(EMS_ENOMEM, "device allocation failed");
+    HIP_TRY(ems_launch_syndrome_unit(drp, dcol, dcf, c->M, c->GF, dd, da, db, dfb, nullptr));
+    unsigned fb = 0;
+    HIP_TRY(hipMemcpy(&fb, dfb, sizeof fb, hipMemcpyDeviceToHost));
+    *synd = fb == 0xFFFFFFFFu ? 0 : (int)(fb & 0xFFu);
+    return EMS_OK;
+}
+
+} // extern "C"

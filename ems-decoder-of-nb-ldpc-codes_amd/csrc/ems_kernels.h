@@ -1,0 +1,27 @@
+// ems_kernels.h -- launchers of the gfx950 kernels (ems_kernels.hip), called by ems_core.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ems_plan.h"
+
+int ems_lpe_for(int dc);                                     // lanes per edge row; 0 = unsupported degree
+size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
+size_t ems_wg_lds_bytes(int q, size_t wave_bytes, int waves);
+
+hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
+hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
+                               const uint8_t *idx2bin_dev, float *app_dev, hipStream_t st);
+hipError_t ems_launch_count_errors(const uint8_t *decide_dev, const int *cw_dev, int B, int N, int K,
+                                   const uint8_t *idx2bin_dev, int *nberr_dev, hipStream_t st);
+hipError_t ems_launch_expand_ctov(const uint8_t *rec_dev, int rec_bytes, int nm, int q, int E, float *out_dev,
+                                  hipStream_t st);
+hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
+                              int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx,
+                              hipStream_t st);
+hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov,
+                              hipStream_t st);
+hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide, hipStream_t st);
+hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
+                                    const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st);

@@ -1,0 +1,701 @@
+// ems_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels of the EMS NB-LDPC hot path.
+//
+// Mapping (wave64 throughout, no MFMA: this is compare/select/merge work, HBM- and VALU-bound):
+//   * one WORKGROUP per frame, persistent over the whole decode (all sweeps, all levels): frames are
+//     independent, so there is no inter-workgroup communication at all; the only synchronisation is
+//     __syncthreads() between the levels of the layered schedule (NB_LDPC.c:320 order is preserved:
+//     check nodes inside a level share no variable node, levels run in order);
+//   * one WAVEFRONT per check-node visit; the 64 lanes are split into dc "edge rows" of LPE lanes
+//     (LPE = 16 for dc <= 4, 8 for dc <= 8); each row owns one edge: its q-wide APP row is read from
+//     HBM with 16-byte coalesced loads and stays in registers (q/LPE values per lane) from the
+//     variable-node extract (NB_LDPC.c:329-337) to the posterior update (NB_LDPC.c:444-450);
+//   * the L-bubble elementary check node (bubble_decoder.c:316) runs on groups of 8 lanes = its 8
+//     competitors; min-of-8 / winner broadcast are DPP butterflies (quad_perm + row_half_mirror),
+//     the GF(q) addition is an XOR of binary images, the "already in output" set is a 256-bit set
+//     spread over the 8 lanes; up to four elementary steps (forward, backward, two merges) of one
+//     check node run side by side in one wave;
+//   * nm-entry sorted (LLR, symbol) lists, the two q-byte field tables and a q-wide staging row per
+//     edge live in LDS; check-to-variable messages live in HBM in a compact nm*5+5 byte record.
+//
+// Bit-exactness: only f32 add/sub/compare on the decode path, compiled with -ffp-contract=off, all
+// tie-breaks (lowest symbol / lowest competitor) and the 1e5 sentinel comparisons as in the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ems_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers (GFX9 DPP controls)
+// ------------------------------------------------------------------------------------------------
+constexpr int DPP_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;     // quad_perm [2,3,0,1]
+constexpr int DPP_HMIRROR = 0x141; // row_half_mirror: lane i <-> 7-i inside each 8
+constexpr int DPP_MIRROR = 0x140;  // row_mirror:      lane i <-> 15-i inside each 16
+
+template <int CTRL> __device__ __forceinline__ int dpp_i(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x)
+{
+    return __int_as_float(dpp_i<CTRL>(__float_as_int(x)));
+}
+
+// all-reduce over aligned groups of 8 lanes (every lane of the group receives the result)
+__device__ __forceinline__ float red8_minf(float x)
+{
+    x = fminf(x, dpp_f<DPP_XOR1>(x));
+    x = fminf(x, dpp_f<DPP_XOR2>(x));
+    x = fminf(x, dpp_f<DPP_HMIRROR>(x));
+    return x;
+}
+__device__ __forceinline__ int red8_mini(int x)
+{
+    x = min(x, dpp_i<DPP_XOR1>(x));
+    x = min(x, dpp_i<DPP_XOR2>(x));
+    x = min(x, dpp_i<DPP_HMIRROR>(x));
+    return x;
+}
+__device__ __forceinline__ unsigned red8_or(unsigned x)
+{
+    x |= (unsigned)dpp_i<DPP_XOR1>((int)x);
+    x |= (unsigned)dpp_i<DPP_XOR2>((int)x);
+    x |= (unsigned)dpp_i<DPP_HMIRROR>((int)x);
+    return x;
+}
+
+// lexicographic (value, symbol) arg-min over a row of LPE lanes; ties -> lowest symbol
+template <int CTRL> __device__ __forceinline__ void argmin_step(float &v, int &g)
+{
+    const float ov = dpp_f<CTRL>(v);
+    const int og = dpp_i<CTRL>(g);
+    const bool take = (ov < v) || (ov == v && og < g);
+    v = take ? ov : v;
+    g = take ? og : g;
+}
+template <int LPE> __device__ __forceinline__ void row_argmin(float &v, int &g)
+{
+    argmin_step<DPP_XOR1>(v, g);
+    argmin_step<DPP_XOR2>(v, g);
+    argmin_step<DPP_HMIRROR>(v, g);
+    if (LPE == 16) argmin_step<DPP_MIRROR>(v, g);
+}
+
+// Lanes of one wave exchange data through LDS; DS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// GF(q) in the exponent domain: index 0 = zero, index i>=1 = alpha^(i-1)  (init.c:65-130)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gf_mul_log(int g, int lh, int qm1)   // MULGF[g][lh+1]
+{
+    int x = g - 1 + lh;
+    x = x >= qm1 ? x - qm1 : x;
+    return g == 0 ? 0 : x + 1;
+}
+__device__ __forceinline__ int gf_div_log(int g, int lh, int qm1)   // DIVGF[g][lh+1]
+{
+    int x = g - 1 - lh;
+    x = x < 0 ? x + qm1 : x;
+    return g == 0 ? 0 : x + 1;
+}
+
+__device__ __forceinline__ unsigned sym_comb(unsigned a, unsigned b)
+{
+    return ((a ^ b) & 0xFFu) | ((a | b) & EMS_S_INVALID);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ElementaryStep (bubble_decoder.c:316-593) on one aligned group of 8 lanes.
+// lists : the wave's LDS message lists, nm entries each.  a_id/b_id/o_id: Input1, Input2, Output list
+// ids; o_id < 0 -> this group has no task in this step (its lanes idle along).
+// Competitor p (= lane & 7): p < 4 sits on row p and walks right (bubble_decoder.c:552-555), p >= 4
+// starts at (4, p-4) and walks down (:548-551).  Each lane keeps its own head (value + packed symbol)
+// and prefetches its next cell, so the only per-step cross-lane traffic is three 8-lane butterflies.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, int a_id, int b_id, int o_id,
+                                         int nm, int nbOper)
+{
+    const int p = lane & 7;
+    const bool has = o_id >= 0;
+    const EmsEntry *in1 = lists + (has ? a_id : 0) * nm;
+    const EmsEntry *in2 = lists + (has ? b_id : 0) * nm;
+    EmsEntry *out = lists + (has ? o_id : 0) * nm;
+
+    if (has)
+        for (int k = p; k < nm; k += 8) out[k] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID}; // :370-374
+
+    const bool rowc = p < 4;
+    const EmsEntry *mv = rowc ? in2 : in1;
+    int pos = rowc ? 0 : 4;
+    const EmsEntry fx = rowc ? in1[p] : in2[p - 4];
+    const EmsEntry h0 = mv[pos];
+    EmsEntry nx = mv[min(pos + 1, nm - 1)];
+    float hv = fx.v + h0.v;                                    // tab_aux[r][c] = In1[r] + In2[c]
+    unsigned hs = sym_comb(fx.s, h0.s) | (pos >= nm - 1 ? EMS_S_BOUND : 0u);
+
+    unsigned bits = 0; // this lane's 32-symbol slice of GFvalues_already_in_Out (:334)
+    int s = 0;
+    bool act = has;
+    for (int ss = 0; ss < nbOper; ++ss) {                      // :472
+        if (__ballot(act) == 0ull) break;
+        // minimum() (:38-56): first strictly smallest head below 1e5, else competitor 0
+        const float m = red8_minf(hv);
+        const bool vmin = m < EMS_SENTINEL;
+        int wp = red8_mini((hv == m) ? p : 8);
+        wp = vmin ? wp : 0;
+        const bool iw = (p == wp);
+        const unsigned wh = red8_or(iw ? hs : 0u);
+        const float wv = vmin ? m : hv;                        // read on lane p == 0 only
+        const unsigned sym = wh & 0xFFu;
+        const bool inv = (wh & EMS_S_INVALID) != 0;            // :478-484 source index -1 -> break
+        const bool bnd = (wh & EMS_S_BOUND) != 0;              // :506 row/col >= nm-1 -> break after
+        const bool mine = (sym >> 5) == (unsigned)p;
+        const unsigned bit = 1u << (sym & 31u);
+        const bool dup = red8_or((mine && (bits & bit)) ? 1u : 0u) != 0; // :490
+        const bool ap = act && !inv && !dup;
+        if (ap && mine) bits |= bit;
+        if (ap && p == 0) out[s] = EmsEntry{wv, sym};          // :492-494
+        s += ap ? 1 : 0;
+        const bool stop = inv || (s == nm) || bnd;             // :484, :502, :506
+        const bool adv = act && !stop && iw;
+        act = act && !stop;
+        if (adv) {                                             // :548-557
+            pos += 1;
+            hv = fx.v + nx.v;
+            hs = sym_comb(fx.s, nx.s) | (pos >= nm - 1 ? EMS_S_BOUND : 0u);
+            nx = mv[min(pos + 1, nm - 1)];
+        }
+    }
+    if (has && p == 0) lens[o_id] = s;
+}
+
+// Forward/backward recursion + merges of CheckPassLogEMS (bubble_decoder.c:166-227) as a static task
+// table: step t runs P[t] = ES(P[t-1], in[t]), S[dc-1-t] = ES(S[dc-t], in[dc-1-t]) and every merge
+// ES(P[k], S[k+2]) whose operands became available after step t-1, side by side on 8-lane groups.
+__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, int lane)
+{
+    const int grp = lane >> 3;
+    for (int t = 0; t < P.nsteps; ++t) {
+        int a = -1, b = -1, o = -1;
+        if (grp < 4) {
+            const int8_t *sc = P.sched + (t * 4 + grp) * 3;
+            a = sc[0]; b = sc[1]; o = sc[2];
+        }
+        es_stage(lists, lens, lane, a, b, o, P.nm, P.nbOper);
+        wave_lds_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry of one wave for field order Q and LPE lanes per edge
+// ------------------------------------------------------------------------------------------------
+template <int Q, int LPE> struct Geo {
+    static constexpr int NROWS = 64 / LPE;
+    static constexpr int EPL = Q / LPE;            // symbols per lane
+    static constexpr int VW = EPL >= 4 ? 4 : EPL;  // floats per vector access
+    static constexpr int NV = EPL / VW;
+    // symbol index of element e of row-lane rl: consecutive lanes own consecutive VW-float vectors
+    __device__ static __forceinline__ int sym_of(int e, int rl) { return (e / VW) * (VW * LPE) + rl * VW + (e % VW); }
+};
+
+template <int VW> struct VecT;
+template <> struct VecT<4> { using T = float4; };
+template <> struct VecT<2> { using T = float2; };
+template <> struct VecT<1> { using T = float; };
+
+template <int Q, int LPE, typename PT> __device__ __forceinline__ void load_row(PT base, int rl, float (&x)[Geo<Q, LPE>::EPL])
+{
+    using G = Geo<Q, LPE>;
+    using V = typename VecT<G::VW>::T;
+#pragma unroll
+    for (int j = 0; j < G::NV; ++j) {
+        const V v = *reinterpret_cast<const V *>(base + j * (G::VW * LPE) + rl * G::VW);
+        const float *pv = reinterpret_cast<const float *>(&v);
+#pragma unroll
+        for (int i = 0; i < G::VW; ++i) x[j * G::VW + i] = pv[i];
+    }
+}
+template <int Q, int LPE, typename PT> __device__ __forceinline__ void store_row(PT base, int rl, const float (&x)[Geo<Q, LPE>::EPL])
+{
+    using G = Geo<Q, LPE>;
+    using V = typename VecT<G::VW>::T;
+#pragma unroll
+    for (int j = 0; j < G::NV; ++j) {
+        V v;
+        float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+        for (int i = 0; i < G::VW; ++i) pv[i] = x[j * G::VW + i];
+        *reinterpret_cast<V *>(base + j * (G::VW * LPE) + rl * G::VW) = v;
+    }
+}
+template <int Q, int LPE, typename PT> __device__ __forceinline__ void fill_row(PT base, int rl, float val)
+{
+    float x[Geo<Q, LPE>::EPL];
+#pragma unroll
+    for (int e = 0; e < Geo<Q, LPE>::EPL; ++e) x[e] = val;
+    store_row<Q, LPE>(base, rl, x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variable-node top-nm selection (NB_LDPC.c:354-374), one edge per row, literal "nm rounds of first
+// strict minimum below 1e5" semantics.  Writes raw (value, symbol index) pairs to list `t`.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int LPE>
+__device__ __forceinline__ void select_rounds(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *raw, int rl, int nm)
+{
+    using G = Geo<Q, LPE>;
+    float w[G::EPL];
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) w[e] = mvc[e];
+    for (int k = 0; k < nm; ++k) {
+        float lv = w[0];
+        int le = 0;
+#pragma unroll
+        for (int e = 1; e < G::EPL; ++e) {
+            const bool lt = w[e] < lv;
+            lv = lt ? w[e] : lv;
+            le = lt ? e : le;
+        }
+        const int myg = G::sym_of(le, rl);
+        float mv = lv;
+        int mg = myg;
+        row_argmin<LPE>(mv, mg);
+        const bool valid = mv < EMS_SENTINEL;                  // :362 strict '<' against 1e5
+        if (rl == 0) raw[k] = EmsEntry{valid ? mv : EMS_SENTINEL, valid ? (unsigned)mg : 0u};
+        const bool owner = valid && (myg == mg);               // :368 mark the winner as taken
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) w[e] = (owner && e == le) ? __builtin_inff() : w[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One check-node visit by one wave: NB_LDPC.c:329-450 around bubble_decoder.c:72-305.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int LPE>
+__device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool first_sweep, const uint8_t *t_i2b,
+                                           const uint8_t *t_b2i, float *dense, EmsEntry *lists, int *lens, int lane)
+{
+    using G = Geo<Q, LPE>;
+    const int rl = lane & (LPE - 1);
+    const int row = lane / LPE;
+    const bool rowact = row < P.dc;
+    const int t = rowact ? row : P.dc - 1;         // idle rows shadow the last edge, stores masked
+    const int nm = P.nm;
+    const int qm1 = Q - 1;
+    const int edge = cn * P.dc + t;
+    const int vn = P.cn_vn[edge];
+    const int lh = P.cn_lh[edge];
+    float *app_row = P.app + ((size_t)f * P.N + vn) * Q;
+    uint8_t *rec = P.ctov + ((size_t)f * P.E + edge) * P.rec_bytes;
+    float *drow = dense + row * Q;
+
+    // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279) ----
+    float mvc[G::EPL];
+    load_row<Q, LPE>(app_row, rl, mvc);
+    if (!first_sweep) {
+        const float dflt = *reinterpret_cast<const float *>(rec + 4 * nm);
+        const int cnt = rec[4 * nm + 4];
+        fill_row<Q, LPE>(drow, rl, dflt);
+        wave_lds_sync();
+        for (int k = rl; k < cnt; k += LPE) drow[rec[4 * nm + 5 + k]] = reinterpret_cast<const float *>(rec)[k];
+        wave_lds_sync();
+        float c[G::EPL];
+        load_row<Q, LPE>(drow, rl, c);
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) mvc[e] = mvc[e] - c[e];
+    }
+
+    // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
+    EmsEntry *inl = lists + t * nm;
+    select_rounds<Q, LPE>(mvc, inl, rl, nm);
+    wave_lds_sync();
+    // ---- normalise (:372-373) and rotate by the edge coefficient (bubble_decoder.c:133-152) ----
+    {
+        constexpr int NT = (EMS_MAX_NM + LPE - 1) / LPE;
+        const float v0 = inl[0].v;
+        EmsEntry tmp[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int k = rl + c * LPE;
+            const EmsEntry r = inl[k < nm ? k : 0];
+            const int gi = gf_mul_log((int)r.s, lh, qm1);
+            tmp[c] = EmsEntry{k == 0 ? 0.0f : r.v - v0, (unsigned)t_i2b[gi]};
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int k = rl + c * LPE;
+            if (rowact && k < nm) inl[k] = tmp[c];
+        }
+    }
+    wave_lds_sync();
+
+    // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
+    cn_core(P, lists, lens, lane);
+
+    // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
+    //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
+    const int oid = P.out_list[t];
+    const EmsEntry *ol = lists + oid * nm;
+    const int stp = (P.dc == 2) ? nm : lens[oid];
+    const float dflt = ol[stp - 1].v + P.offset;
+    fill_row<Q, LPE>(drow, rl, dflt);
+    wave_lds_sync();
+    for (int k = rl; k < stp; k += LPE) {
+        const EmsEntry e = ol[k];
+        const int g = gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1);
+        drow[g] = e.v;
+        if (rowact) {
+            reinterpret_cast<float *>(rec)[k] = e.v;
+            rec[4 * nm + 5 + k] = (uint8_t)g;
+        }
+    }
+    if (rowact && rl == 0) {
+        *reinterpret_cast<float *>(rec + 4 * nm) = dflt;
+        rec[4 * nm + 4] = (uint8_t)stp;
+    }
+    wave_lds_sync();
+    float napp[G::EPL];
+    load_row<Q, LPE>(drow, rl, napp);
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) napp[e] = napp[e] + mvc[e];
+    if (rowact) store_row<Q, LPE>(app_row, rl, napp);
+
+    // ---- Decision (tools.c:312-330) of this variable node; the later visit of the sweep wins ----
+    float lv = EMS_SENTINEL;
+    int lg = 0x7FFFFFFF;
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) {
+        const bool lt = napp[e] < lv;
+        lv = lt ? napp[e] : lv;
+        lg = lt ? G::sym_of(e, rl) : lg;
+    }
+    row_argmin<LPE>(lv, lg);
+    if (rowact && rl == 0) P.decide[(size_t)f * P.N + vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
+    wave_lds_sync();
+}
+
+// LDS carve of a workgroup: [idx2bin Q][bin2idx Q][first-nonzero-syndrome word, padded to 16] then one
+// region per wave: dense rows | lists | lens.
+template <int Q> __device__ __forceinline__ constexpr int wg_header_bytes() { return 2 * Q + 16; }
+
+// ------------------------------------------------------------------------------------------------
+// The decode kernel: one workgroup per frame, persistent over all sweeps.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int LPE>
+__global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
+{
+    using G = Geo<Q, LPE>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *t_i2b = smem;
+    uint8_t *t_b2i = smem + Q;
+    unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int f = blockIdx.x;
+
+    uint8_t *wbase = smem + wg_header_bytes<Q>() + (size_t)wave * P.wave_lds_bytes;
+    float *dense = reinterpret_cast<float *>(wbase);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
+    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + ((P.n_lists * P.nm * 8 + 15) & ~15));
+
+    for (int i = tid; i < Q; i += blockDim.x) {
+        t_i2b[i] = P.idx2bin[i];
+        t_b2i[i] = P.bin2idx[i];
+    }
+    if (tid == 0) *first_bad = 0xFFFFFFFFu;
+    __syncthreads();
+
+    int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
+    unsigned synd = 0;
+    for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
+        for (int lv = 0; lv < P.n_levels; ++lv) {              // NB_LDPC.c:320, level by level
+            const int b = P.lvl_ptr[lv], e = P.lvl_ptr[lv + 1];
+            for (int i = b + wave; i < e; i += nwaves)
+                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, lists, lens, lane);
+            __syncthreads();
+        }
+        // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero
+        //      sum; 0 iff codeword.  One thread per check node.
+        for (int c = tid; c < P.M; c += blockDim.x) {
+            unsigned acc = 0;
+            for (int i = 0; i < P.dc; ++i) {
+                const int ed = c * P.dc + i;
+                const int x = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
+                acc ^= t_i2b[gf_mul_log(x, P.cn_lh[ed], Q - 1)];
+            }
+            if (acc) atomicMin(first_bad, ((unsigned)c << 8) | t_b2i[acc]);
+        }
+        __syncthreads();
+        const unsigned fb = *first_bad;
+        __syncthreads();
+        if (tid == 0) *first_bad = 0xFFFFFFFFu;
+        synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        if (synd == 0 && P.early_exit) {                       // NB_LDPC.c:470-471
+            it = sweep + 1;
+            break;
+        }
+    }
+    if (tid == 0) {
+        P.iters[f] = it;
+        P.synd[f] = (int)synd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel LLR (channel.c:66-76): one thread per (frame, variable node, symbol).  The float/double
+// promotion order of the reference expression is kept term by term.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_llr_init(const float *__restrict__ noisy, float sigma, int logq, int q, size_t total,
+                           const uint8_t *__restrict__ idx2bin, float *__restrict__ app)
+{
+    const double denom = 2.0 * (double)(sigma * sigma);        // 2.0*SQR(sigma), SQR in float
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t fn = i / q;
+        const int g = (int)(i - fn * q);
+        const unsigned img = idx2bin[g];
+        const float *y = noisy + fn * logq;
+        float t = 0.0f;
+        for (int l = 0; l < logq; ++l) {
+            const float s = ((img >> l) & 1u) ? -1.0f : 1.0f;  // BPSK(x) = 1-2x (channel.h:14)
+            const float a = y[l] - s;
+            const float sq = a * a;
+            t = (float)((double)t + (double)sq / denom);
+        }
+        app[i] = t;
+    }
+}
+
+// NB_LDPC.c:479-485: bit errors between decide[k] and the codeword over the first K symbols
+__global__ void k_count_errors(const uint8_t *__restrict__ decide, const int *__restrict__ cw, int N, int K,
+                               const uint8_t *__restrict__ idx2bin, int *__restrict__ nberr)
+{
+    const int f = blockIdx.x;
+    int acc = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+        acc += __popc((unsigned)(idx2bin[decide[(size_t)f * N + k]] ^ idx2bin[cw[(size_t)f * N + k]]));
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    __shared__ int part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+        nberr[f] = s;
+    }
+}
+
+// decoder_t.CtoV as the reference keeps it (dense [E][q]) from the compact records, for parity tests
+__global__ void k_expand_ctov(const uint8_t *__restrict__ rec_base, int rec_bytes, int nm, int q, int E,
+                              float *__restrict__ out)
+{
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    const uint8_t *rec = rec_base + (size_t)e * rec_bytes;
+    const float dflt = *reinterpret_cast<const float *>(rec + 4 * nm);
+    const int cnt = rec[4 * nm + 4];
+    for (int g = threadIdx.x; g < q; g += blockDim.x) out[(size_t)e * q + g] = dflt;
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x)
+        out[(size_t)e * q + rec[4 * nm + 5 + k]] = reinterpret_cast<const float *>(rec)[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-node kernels (one wave) behind the reference-shaped ElementaryStep / CheckPassLogEMS /
+// Decision / Syndrom symbols: same device functions as the decode kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
+                          int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx)
+{
+    __shared__ EmsEntry lists[3 * EMS_MAX_NM];
+    __shared__ int lens[4];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < nm; k += 64) {
+        lists[k] = EmsEntry{in1[k], idx1[k] < 0 ? EMS_S_INVALID : (unsigned)idx2bin[idx1[k]]};
+        lists[nm + k] = EmsEntry{in2[k], idx2[k] < 0 ? EMS_S_INVALID : (unsigned)idx2bin[idx2[k]]};
+    }
+    wave_lds_sync();
+    const bool g0 = lane < 8;
+    es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+    wave_lds_sync();
+    for (int k = lane; k < nm; k += 64) {
+        const EmsEntry e = lists[2 * nm + k];
+        out[k] = e.v;
+        idxout[k] = (e.s & EMS_S_INVALID) ? -1 : (int)bin2idx[e.s & 0xFFu];
+    }
+}
+
+template <int Q>
+__global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(smem);
+    int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * P.nm * 8 + 15) & ~15));
+    const int lane = threadIdx.x;
+    const int nm = P.nm, dc = P.dc;
+    for (int i = lane; i < dc * nm; i += 64) {                 // rotation, bubble_decoder.c:133-152
+        const int t = i / nm;
+        const int g = vtoc_gf[i];
+        lists[i] = EmsEntry{vtoc_llr[i], g < 0 ? EMS_S_INVALID : (unsigned)P.idx2bin[gf_mul_log(g, coef[t] - 1, Q - 1)]};
+    }
+    wave_lds_sync();
+    cn_core(P, lists, lens, lane);
+    for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
+        const int oid = P.out_list[t];
+        const EmsEntry *ol = lists + oid * nm;
+        const int stp = (dc == 2) ? nm : lens[oid];
+        const float dflt = ol[stp - 1].v + P.offset;
+        for (int g = lane; g < Q; g += 64) ctov[t * Q + g] = dflt;
+        __threadfence_block();
+        for (int k = lane; k < stp; k += 64)
+            ctov[t * Q + gf_div_log((int)P.bin2idx[ol[k].s & 0xFFu], coef[t] - 1, Q - 1)] = ol[k].v;
+    }
+}
+
+__global__ void k_decision_unit(const float *__restrict__ app, int N, int q, int *__restrict__ decide)
+{
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float lv = EMS_SENTINEL;
+    int lg = 0x7FFFFFFF;
+    for (int g = lane; g < q; g += 64) {
+        const float v = app[(size_t)n * q + g];
+        if (v < lv) { lv = v; lg = g; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(lv, o);
+        const int og = __shfl_xor(lg, o);
+        if (ov < lv || (ov == lv && og < lg)) { lv = ov; lg = og; }
+    }
+    if (lane == 0) decide[n] = lv < EMS_SENTINEL ? lg : 0;
+}
+
+__global__ void k_syndrome_unit(const int *__restrict__ row_ptr, const int *__restrict__ col, const int *__restrict__ coef,
+                                int M, int q, const int *__restrict__ decide, const uint8_t *__restrict__ idx2bin,
+                                const uint8_t *__restrict__ bin2idx, unsigned *first_bad)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < M; c += gridDim.x * blockDim.x) {
+        unsigned acc = 0;
+        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e) acc ^= idx2bin[gf_mul_log(decide[col[e]], coef[e] - 1, q - 1)];
+        if (acc) atomicMin(first_bad, ((unsigned)c << 8) | bin2idx[acc]);
+    }
+}
+
+template <typename T> hipError_t set_max_lds(T kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+} // namespace
+
+// ================================================================================================
+// host-side launchers
+// ================================================================================================
+int ems_lpe_for(int dc) { return dc <= 4 ? 16 : (dc <= 8 ? 8 : 0); }
+
+size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
+{
+    const int lpe = ems_lpe_for(dc);
+    if (!lpe) return 0;
+    const size_t dense = (size_t)(64 / lpe) * q * 4;
+    const size_t lists = ((size_t)n_lists * nm * 8 + 15) & ~(size_t)15;
+    const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
+    return dense + lists + lens;
+}
+
+size_t ems_wg_lds_bytes(int q, size_t wave_bytes, int waves) { return (size_t)2 * q + 16 + wave_bytes * waves; }
+
+template <int Q, int LPE> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    const size_t lds = ems_wg_lds_bytes(Q, P.wave_lds_bytes, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode<Q, LPE>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
+{
+    const int lpe = ems_lpe_for(P.dc);
+    if (lpe == 16) {
+        if (P.q == 256) return launch_decode_t<256, 16>(P, B, st);
+        if (P.q == 64) return launch_decode_t<64, 16>(P, B, st);
+        if (P.q == 16) return launch_decode_t<16, 16>(P, B, st);
+    } else if (lpe == 8) {
+        if (P.q == 256) return launch_decode_t<256, 8>(P, B, st);
+        if (P.q == 64) return launch_decode_t<64, 8>(P, B, st);
+        if (P.q == 16) return launch_decode_t<16, 8>(P, B, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
+                               const uint8_t *idx2bin_dev, float *app_dev, hipStream_t st)
+{
+    const int threads = 256;
+    size_t blocks = (total + threads - 1) / threads;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(threads), 0, st, noisy_dev, sigma, logq, q, total,
+                       idx2bin_dev, app_dev);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_count_errors(const uint8_t *decide_dev, const int *cw_dev, int B, int N, int K,
+                                   const uint8_t *idx2bin_dev, int *nberr_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_count_errors, dim3(B), dim3(256), 0, st, decide_dev, cw_dev, N, K, idx2bin_dev, nberr_dev);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_expand_ctov(const uint8_t *rec_dev, int rec_bytes, int nm, int q, int E, float *out_dev,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(k_expand_ctov, dim3(E), dim3(64), 0, st, rec_dev, rec_bytes, nm, q, E, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
+                              int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(k_es_unit, dim3(1), dim3(64), 0, st, in1, in2, idx1, idx2, out, idxout, nm, nbOper, idx2bin,
+                       bin2idx);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov,
+                              hipStream_t st)
+{
+    const size_t lds = (((size_t)P.n_lists * P.nm * 8 + 15) & ~(size_t)15) + (((size_t)P.n_lists * 4 + 15) & ~(size_t)15);
+    if (P.q == 256) hipLaunchKernelGGL((k_cn_unit<256>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
+    else if (P.q == 64) hipLaunchKernelGGL((k_cn_unit<64>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
+    else if (P.q == 16) hipLaunchKernelGGL((k_cn_unit<16>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decision_unit, dim3((N + 3) / 4), dim3(256), 0, st, app, N, q, decide);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
+                                    const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_syndrome_unit, dim3((M + 255) / 256), dim3(256), 0, st, row_ptr, col, coef, M, q, decide,
+                       idx2bin, bin2idx, first_bad);
+    return hipGetLastError();
+}

@@ -1,0 +1,58 @@
+// ems_plan.h -- data shared between the host orchestration (ems_core.cpp) and the gfx950 kernels
+// (ems_kernels.hip).  Plain structs only.
+#pragma once
+#include <stdint.h>
+
+// One message entry as it lives in LDS during a check-node visit: the LLR and the GF symbol in the
+// *binary-image* domain (GF addition == XOR there, which replaces the q*q ADDGF table of
+// init.c:37-55).  bit 8 of `s` marks an invalid entry (the reference's symbol index -1 paired with the
+// value 1e5, bubble_decoder.c:370-374); bit 9 is used transiently inside the bubble loop.
+struct EmsEntry {
+    float v;
+    uint32_t s;
+};
+
+#define EMS_SENTINEL 1e5f
+#define EMS_S_INVALID 0x100u
+#define EMS_S_BOUND 0x200u
+#define EMS_MAX_NM 32      // messages longer than this are not built (reference usage: 8..30)
+#define EMS_MAX_STEPS 14   // dc-2 forward/backward steps (dc <= 16)
+
+// Compact check-to-variable record kept in HBM per (frame, edge).  The reference stores a dense
+// q-wide float row per edge (init.c:323-328) although a C->V message is nm (LLR, symbol) pairs plus
+// one default value (bubble_decoder.c:262-278); the values are copies, never re-summed, so the compact
+// form is bit-exact.  Layout (bytes): [0,4nm) float vals[nm]; [4nm,4nm+4) float dflt;
+// [4nm+4] uint8 cnt; [4nm+5, 5nm+5) uint8 sym[nm] (symbol INDEX after the inverse rotation);
+// padded to a multiple of 16.
+static inline int ems_rec_bytes(int nm) { return ((5 * nm + 5) + 15) & ~15; }
+
+struct EmsPlan {
+    // code
+    int N, M, E, q, logq, dc;
+    // decoder parameters
+    int nm, nbOper, nsweeps, early_exit;
+    float offset;
+    // schedule: check nodes grouped in levels; no two in a level share a variable node
+    int n_levels;
+    const int *lvl_ptr;     // [n_levels+1]
+    const int *lvl_cn;      // [M]
+    const int *cn_vn;       // [M*dc] variable node of edge (cn*dc+i)      (code_t.mat)
+    const uint8_t *cn_lh;   // [M*dc] log_alpha of the edge coefficient = index-1 (code_t.matValue)
+    // forward/backward/merge task table: [nsteps][4][3] = (in1 list, in2 list, out list) or -1
+    int nsteps;
+    const int8_t *sched;
+    int8_t out_list[16];    // list id holding the output for edge t
+    int n_lists;
+    // field tables
+    const uint8_t *idx2bin;
+    const uint8_t *bin2idx;
+    // per-batch state in HBM
+    float *app;             // [B][N][q]
+    uint8_t *ctov;          // [B][E][rec_bytes]
+    uint8_t *decide;        // [B][N]
+    int *iters;             // [B]
+    int *synd;              // [B]
+    int rec_bytes;
+    int wave_lds_bytes;     // LDS per wave
+    int waves_per_wg;
+};

@@ -1,0 +1,127 @@
+/*
+ * ems_abi.h -- C ABI of the MI355X EMS NB-LDPC decoder library (libems_hip.so).
+ *
+ * Plain pointers and sizes only; no C++ / torch / HIP types cross this boundary.  All functions
+ * return 0 on success or a negative EMS_E* code (the reference printf()s and exit()s instead, e.g.
+ * init.c:431-435, tools.c:181-185; this library never exits the process).
+ *
+ * The batched entry points below are NEW: the reference decodes one frame at a time inline in main()
+ * (NB_LDPC.c:266-472).  They are what the GPU path really uses; the reference-shaped single-frame
+ * symbols (Decoding(), CheckPassLogEMS(), ... see nbldpc_ref_api.h) are thin wrappers over them.
+ *
+ * Every compute entry point runs hand-written HIP kernels on gfx950.  There is no CPU fallback: if
+ * no HIP device is usable the calls fail with EMS_ENODEV.
+ */
+#ifndef EMS_ABI_H
+#define EMS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    EMS_OK = 0,
+    EMS_EINVAL = -1,     /* bad argument / unsupported parameter combination                         */
+    EMS_ENODEV = -2,     /* no usable HIP device (the library has NO CPU fallback)                   */
+    EMS_EHIP = -3,       /* a HIP runtime call or kernel launch failed (see ems_last_error)          */
+    EMS_EIO = -4,        /* matrix file unreadable / malformed                                       */
+    EMS_ENOMEM = -5,
+    EMS_EUNSUPPORTED = -6 /* field order, check degree or nm outside what the kernels are built for */
+};
+
+/* ---- parity-check matrix, flat CSR by check node (what init.c:143-272 LoadCode parses) ---- */
+typedef struct {
+    int N, M, GF, logGF;   /* code_t.N/.M/.GF/.logGF (struct.h:48-64)                               */
+    int nbBranch;          /* number of edges E                                                     */
+    const int *rowDegree;  /* [M]                                                                   */
+    const int *col;        /* [E] variable-node index of each edge, check-node major (code_t.mat)   */
+    const int *coef;       /* [E] GF coefficient as symbol index 1..GF-1 (code_t.matValue)          */
+} ems_code_desc;
+
+/* ---- decoder parameters: the reference's argv (NB_LDPC.c:105-111) ---- */
+typedef struct {
+    int nm;          /* decoder.nbMax: length of the truncated messages                            */
+    int nbOper;      /* NbOper: max bubble-check steps per elementary check node                    */
+    float offset;    /* offset added to the default C->V value (bubble_decoder.c:264)               */
+    int NbIterMax;   /* reference semantics: NbIterMax-1 sweeps are run (NB_LDPC.c:314)             */
+    int early_exit;  /* 1 = stop a frame at the first zero syndrome (NB_LDPC.c:470); 0 = fixed work */
+} ems_params;
+
+typedef struct ems_handle ems_handle;
+
+/* Loader that accepts BOTH on-disk layouts the reference needs a recompile for (init.c:25):
+ * fmt 0 = auto-detect, 1 = "UBS" block layout (init.c:195-207), 2 = "KN" interleaved (init.c:211-227).
+ * Arrays are malloc()ed into *desc; release with ems_free_code_desc. */
+int ems_load_code_file(const char *path, int fmt, ems_code_desc *desc);
+void ems_free_code_desc(ems_code_desc *desc);
+
+/* GF(q) tables as the reference builds them (init.c:37-130, struct.h:117-476); q in {16,64,256}.
+ * idx2bin[i] = binary image of symbol index i (bit l = BINGF[i][l]); bin2idx = inverse. */
+int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
+
+/* Create a decoder for one code on HIP device `device`, sized for up to max_batch frames in flight. */
+int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *prm, int max_batch, int device);
+void ems_destroy(ems_handle *h);
+int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */
+
+/* ---- the hot path, batched.  B <= max_batch frames.  Host-pointer variants copy in/out. ---- */
+
+/* channel.c:66-76 (GF(q) LLR of every symbol of every variable node) -> APP (NB_LDPC.c:281-288).
+ * noisy: [B][N][logGF] float BPSK+AWGN observations (host-generated so the drand48 stream is kept). */
+int ems_llr_init(ems_handle *h, const float *noisy_host, float sigma, int B);
+int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B);
+/* Alternative input for tests: load APP directly from [B][N][GF] LLRs indexed by symbol. */
+int ems_load_llr(ems_handle *h, const float *llr_host, int B);
+
+/* NB_LDPC.c:266-472 for B frames: all sweeps, per-sweep Decision + Syndrom, per-frame early exit. */
+int ems_decode(ems_handle *h, int B);
+
+/* Results of the last ems_decode: decide [B][N] (tools.c:312), iters [B] = iter+1 (NB_LDPC.c:474),
+ * synd [B] = value Syndrom() returns (tools.c:284).  Any pointer may be NULL. */
+int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd);
+
+/* llr_init + decode + get_results in one call (what Decoding() and the harness use). */
+int ems_decode_batch(ems_handle *h, const float *noisy_host, float sigma, int B,
+                     int *decide, int *iters, int *synd);
+
+/* NB_LDPC.c:479-485 bit errors over the first K symbols against the transmitted codewords [B][N]. */
+int ems_count_errors(ems_handle *h, const int *codewords_host, int B, int *nb_errors /*[B]*/);
+
+/* ---- introspection for parity tests ---- */
+int ems_get_app(ems_handle *h, int frame, float *app /*[N][GF]*/);   /* decoder_t.APP after decode      */
+int ems_get_ctov(ems_handle *h, int frame, float *ctov /*[E][GF]*/); /* decoder_t.CtoV, expanded dense */
+/* Level schedule of the layered sweep: check nodes grouped so that no two in a level share a variable
+ * node; visiting levels in order reproduces the sequential order of NB_LDPC.c:320 exactly. */
+int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr /*[M+1] or NULL*/, int *order /*[M] or NULL*/);
+
+/* ---- single-node entry points on the device (unit parity of bubble_decoder.c) ---- */
+/* bubble_decoder.c:316 ElementaryStep: index-domain symbols, -1 = invalid, 1e5 = padding value. */
+int ems_elementary_step(int GF, int nm, int nbOper, const float *in1, const float *in2, const int *idx1,
+                        const int *idx2, float *out, int *idxout, int device);
+/* bubble_decoder.c:72 CheckPassLogEMS: vtoc_* [dc][nm] sorted+normalised inputs (unrotated symbols),
+ * coef [dc] symbol indices, ctov [dc][GF] dense output indexed by symbol. */
+int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *coef, const float *vtoc_llr,
+                   const int *vtoc_gf, float *ctov, int device);
+/* tools.c:312 / tools.c:284 on the device for one frame */
+int ems_decision(int GF, int N, const float *app /*[N][GF]*/, int *decide, int device);
+int ems_syndrome(const ems_code_desc *code, const int *decide, int *synd, int device);
+
+/* ---- measurement ---- */
+/* Duration in ms of the kernels of the last ems_llr_init / ems_decode call, from HIP events recorded
+ * on the handle's own stream around the launches. */
+float ems_last_llr_ms(const ems_handle *h);
+float ems_last_decode_ms(const ems_handle *h);
+/* Raw device access for zero-copy drivers (bench.py): device pointer of the noisy-sample staging
+ * buffer [max_batch][N][logGF] float and the handle's stream (hipStream_t as void*). */
+void *ems_noisy_dev_ptr(ems_handle *h);
+void *ems_stream(ems_handle *h);
+int ems_synchronize(ems_handle *h);
+const char *ems_last_error(void);
+const char *ems_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMS_ABI_H */
