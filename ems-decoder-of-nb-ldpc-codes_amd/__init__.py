@@ -80,6 +80,8 @@ def lib():
         L.ems_get_ctov.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.ems_synchronize.argtypes = [C.c_void_p]
+        L.ems_level_schedule.argtypes = [C.POINTER(CodeDesc), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.ems_get_sorted_llr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ems_load_code_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(CodeDesc)]
         L.ems_free_code_desc.argtypes = [C.POINTER(CodeDesc)]
         L.ems_gf_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
@@ -119,6 +121,15 @@ class Code:
             lib().ems_free_code_desc(C.byref(self.desc))
         except Exception:
             pass
+
+
+def level_schedule(code):
+    """(level_ptr, order) of the layered sweep, computed on the host (no device needed)."""
+    nl = C.c_int(0)
+    lp = np.zeros(code.M + 1, np.int32)
+    order = np.zeros(code.M, np.int32)
+    _check(lib().ems_level_schedule(C.byref(code.desc), C.byref(nl), _ptr(lp), _ptr(order)))
+    return lp[: nl.value + 1].copy(), order
 
 
 def gf_tables(q):
@@ -205,6 +216,13 @@ class Decoder:
         a = np.zeros((self.code.E, self.code.GF), np.float32)
         _check(lib().ems_get_ctov(self.h, frame, _ptr(a)))
         return a
+
+    def sorted_llr(self, frame):
+        """decoder_t.intrinsic_LLR / intrinsic_GF of one frame (channel.c:78-91), sorted on the GPU."""
+        sl = np.zeros((self.code.N, self.code.GF), np.float32)
+        sg = np.zeros((self.code.N, self.code.GF), np.int32)
+        _check(lib().ems_get_sorted_llr(self.h, frame, _ptr(sl), _ptr(sg)))
+        return sl, sg
 
     def schedule(self):
         nl = C.c_int(0)

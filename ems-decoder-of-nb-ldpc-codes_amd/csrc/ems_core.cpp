@@ -116,6 +116,40 @@ int build_cn_schedule(int dc, CnSchedule &s)
     return EMS_OK;
 }
 
+
+// Level schedule of the layered sweep: level(c) = 1 + max level of the EARLIER check nodes (reference
+// order, NB_LDPC.c:320) that share a variable node with c.  Check nodes inside a level touch disjoint
+// APP rows, and CtoV rows are private to their check node (NB_LDPC.c:438), so visiting the levels in
+// order -- in any order inside a level -- is the sequential sweep exactly.
+int level_schedule(const ems_code_desc *c, std::vector<int> &lvl_ptr, std::vector<int> &lvl_cn)
+{
+    std::vector<int> vn_level(c->N, -1), level(c->M, 0);
+    int nlev = 0;
+    long e0 = 0;
+    for (int m = 0; m < c->M; ++m) {
+        const int dc = c->rowDegree[m];
+        int lv = 0;
+        for (int i = 0; i < dc; ++i) {
+            const int v = c->col[e0 + i], cf = c->coef[e0 + i];
+            if (v < 0 || v >= c->N || cf < 1 || cf >= c->GF) return fail(EMS_EINVAL, "edge %ld out of range", e0 + i);
+            for (int j = 0; j < i; ++j)
+                if (c->col[e0 + j] == v) return fail(EMS_EUNSUPPORTED, "check node %d lists variable node %d twice", m, v);
+            lv = std::max(lv, vn_level[v] + 1);
+        }
+        level[m] = lv;
+        for (int i = 0; i < dc; ++i) vn_level[c->col[e0 + i]] = lv;
+        nlev = std::max(nlev, lv + 1);
+        e0 += dc;
+    }
+    lvl_ptr.assign(nlev + 1, 0);
+    for (int m = 0; m < c->M; ++m) ++lvl_ptr[level[m] + 1];
+    for (int l = 0; l < nlev; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
+    lvl_cn.resize(c->M);
+    std::vector<int> fill(lvl_ptr.begin(), lvl_ptr.end() - 1);
+    for (int m = 0; m < c->M; ++m) lvl_cn[fill[level[m]]++] = m;
+    return EMS_OK;
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -335,35 +369,11 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     if (h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 
-    // Level schedule: level(c) = 1 + max level of the earlier check nodes that share a variable node.
-    // Visiting levels in order (any order inside a level) is the sequential order of NB_LDPC.c:320
-    // as far as every APP row is concerned; CtoV rows are private to their check node (:438).
+    // Edge tables + level schedule (see level_schedule above).
     h->cn_vn.assign(c->col, c->col + E);
     h->cn_lh.resize(E);
-    std::vector<int> vn_level(h->N, -1), level(h->M, 0);
-    int nlev = 0;
-    for (int m = 0; m < h->M; ++m) {
-        int lv = 0;
-        for (int i = 0; i < h->dc; ++i) {
-            const int e = m * h->dc + i, v = c->col[e], cf = c->coef[e];
-            if (v < 0 || v >= h->N || cf < 1 || cf >= h->q) return bail(fail(EMS_EINVAL, "edge %d out of range", e));
-            for (int j = 0; j < i; ++j)
-                if (c->col[m * h->dc + j] == v) return bail(fail(EMS_EUNSUPPORTED, "check node %d lists variable node %d twice", m, v));
-            h->cn_lh[e] = (uint8_t)(cf - 1);
-            lv = std::max(lv, vn_level[v] + 1);
-        }
-        level[m] = lv;
-        for (int i = 0; i < h->dc; ++i) vn_level[c->col[m * h->dc + i]] = lv;
-        nlev = std::max(nlev, lv + 1);
-    }
-    h->lvl_ptr.assign(nlev + 1, 0);
-    for (int m = 0; m < h->M; ++m) ++h->lvl_ptr[level[m] + 1];
-    for (int l = 0; l < nlev; ++l) h->lvl_ptr[l + 1] += h->lvl_ptr[l];
-    h->lvl_cn.resize(h->M);
-    {
-        std::vector<int> fill(h->lvl_ptr.begin(), h->lvl_ptr.end() - 1);
-        for (int m = 0; m < h->M; ++m) h->lvl_cn[fill[level[m]]++] = m;
-    }
+    for (long e = 0; e < E; ++e) h->cn_lh[e] = (uint8_t)(c->coef[e] - 1);
+    if ((r = level_schedule(c, h->lvl_ptr, h->lvl_cn))) return bail(r);
 
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
@@ -500,6 +510,37 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov)
     HIP_TRY(ems_launch_expand_ctov(h->d_ctov.p + (size_t)frame * h->E * rb, rb, h->nm_alloc, h->q, h->E, h->d_scratch.p, h->stream));
     HIP_TRY(hipMemcpyAsync(ctov, h->d_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+
+int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf)
+{
+    int r = check_batch(h, frame + 1);
+    if (r) return r;
+    if (!s_llr || !s_gf || frame < 0) return fail(EMS_EINVAL, "bad argument");
+    const size_t n = (size_t)h->N * h->q;
+    Tmp t;
+    float *dl = t.up<float>(nullptr, n);
+    int *dg = t.up<int>(nullptr, n);
+    if (!dl || !dg) return fail(EMS_ENOMEM, "device allocation failed");
+    HIP_TRY(ems_launch_sort_llr(h->d_app.p + (size_t)frame * n, h->N, h->q, dl, dg, h->stream));
+    HIP_TRY(hipMemcpyAsync(s_llr, dl, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(s_gf, dg, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+
+int ems_level_schedule(const ems_code_desc *code, int *n_levels, int *level_ptr, int *order)
+{
+    if (!code || !code->rowDegree || !code->col || !code->coef) return fail(EMS_EINVAL, "incomplete code description");
+    std::vector<int> lp, lc;
+    int r = level_schedule(code, lp, lc);
+    if (r) return r;
+    if (n_levels) *n_levels = (int)lp.size() - 1;
+    if (level_ptr) memcpy(level_ptr, lp.data(), sizeof(int) * lp.size());
+    if (order) memcpy(order, lc.data(), sizeof(int) * lc.size());
     return EMS_OK;
 }
 

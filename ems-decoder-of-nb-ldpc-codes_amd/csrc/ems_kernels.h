@@ -25,3 +25,4 @@ hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vt
 hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide, hipStream_t st);
 hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
                                     const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st);
+hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_dev, int *s_gf_dev, hipStream_t st);

@@ -496,6 +496,28 @@ __global__ void k_count_errors(const uint8_t *__restrict__ decide, const int *__
     }
 }
 
+// channel.c:78-91: ascending (value, symbol) order of one variable node's q LLRs, as a stable rank by
+// counting (== q rounds of "first strict minimum below 1e5"); values >= 1e5 come out as (1e5, -1).
+__global__ void k_sort_llr(const float *__restrict__ app, int q, float *__restrict__ s_llr, int *__restrict__ s_gf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float *v = reinterpret_cast<float *>(smem);
+    const size_t base = (size_t)blockIdx.x * q;
+    for (int g = threadIdx.x; g < q; g += blockDim.x) v[g] = app[base + g];
+    __syncthreads();
+    for (int i = threadIdx.x; i < q; i += blockDim.x) {
+        const float vi = v[i];
+        int rank = 0;
+        for (int j = 0; j < q; ++j) {
+            const float vj = v[j];
+            rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0;
+        }
+        const bool ok = vi < EMS_SENTINEL;
+        s_llr[base + rank] = ok ? vi : EMS_SENTINEL;
+        s_gf[base + rank] = ok ? i : -1;
+    }
+}
+
 // decoder_t.CtoV as the reference keeps it (dense [E][q]) from the compact records, for parity tests
 __global__ void k_expand_ctov(const uint8_t *__restrict__ rec_base, int rec_bytes, int nm, int q, int E,
                               float *__restrict__ out)
@@ -697,5 +719,11 @@ hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const in
 {
     hipLaunchKernelGGL(k_syndrome_unit, dim3((M + 255) / 256), dim3(256), 0, st, row_ptr, col, coef, M, q, decide,
                        idx2bin, bin2idx, first_bad);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_dev, int *s_gf_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sort_llr, dim3(N), dim3(64), (size_t)q * 4, st, app_dev, q, s_llr_dev, s_gf_dev);
     return hipGetLastError();
 }

@@ -1,0 +1,159 @@
+/*
+ * ems_sim.c -- Monte-Carlo BER/FER harness in C driving the MI355X decoder library.
+ *
+ * Same seven positional arguments, same drand48 draw order (source -> encoder -> channel, frame after
+ * frame, never reseeded), same progress line, same 40-erroneous-frame stop and same result-file line as
+ * the reference's main() (NB_LDPC.c:63-604).  The only structural change is the one north_star asks
+ * for: the inline per-frame decode block (NB_LDPC.c:266-472) is replaced by one batched call into the
+ * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH), decoded
+ * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
+ *
+ *   ems_sim NbMonteCarlo NbIterMax FileMatrix EbN NbMax Offset NbOper
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "ems_abi.h"
+#include "nbldpc_ref_api.h"
+
+static void die(const char *what, int rc)
+{
+    fprintf(stderr, "\n%s failed (%d): %s\n", what, rc, ems_last_error());
+    exit(EXIT_FAILURE);
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc < 8) {
+        printf("File:\n %s\n ", argv[0]);
+        printf("\n\tSyntax:\n\t\n\t NbMonteCarlo     : # simulated frames"
+               "\n\t NbIterMax        : # of maximum decoding iterations"
+               "\n\t FileMatrix       : File name of the parity-check matrix"
+               "\n\t EbN              : Eb/No (dB)"
+               "\n\t NbMax            : size of truncated messages"
+               "\n\t Offset           : offset correction factor (0.4 -- 1)"
+               "\n\t NbOper           : Maximum number of operations for sorting \n");
+        return EXIT_FAILURE;
+    }
+    const int NbMonteCarlo = atoi(argv[1]);
+    const int NbIterMax = atoi(argv[2]);
+    char *FileMatrix = argv[3];
+    const float EbN = (float)atof(argv[4]);
+    const int nbMax = atoi(argv[5]);
+    const float offset = (float)atof(argv[6]);
+    const int NbOper = atoi(argv[7]);
+    int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 64;
+    if (batch < 1) batch = 1;
+    const int device = getenv("EMS_DEVICE") ? atoi(getenv("EMS_DEVICE")) : 0;
+    int Idum = -1;
+
+    printf(" Monte-Carlo simulation of Non-Binary LDPC decoder \n\n");
+    printf("Simulation parameters:\n");
+    printf("\n\t NbMonteCarlo     : %d", NbMonteCarlo);
+    printf("\n\t NbIterMax        : %d", NbIterMax);
+    printf("\n\t FileMatrix       : %s", FileMatrix);
+    printf("\n\t Eb/No (dB)       : %g", EbN);
+    printf("\n\t NbMax            : %d", nbMax);
+    printf("\n\t Offset           : %g", offset);
+    printf("\n\t NbOper           : %d\n", NbOper);
+
+    code_t code;
+    table_t table;
+    LoadCode(FileMatrix, &code);
+    LoadTables(&table, code.GF, code.logGF);
+    GaussianElimination(&code, &table);
+
+    /* flat description for the batched GPU decoder */
+    int *col = malloc(sizeof(int) * (size_t)code.nbBranch), *coef = malloc(sizeof(int) * (size_t)code.nbBranch);
+    for (int m = 0, e = 0; m < code.M; m++)
+        for (int k = 0; k < code.rowDegree[m]; k++, e++) {
+            col[e] = code.mat[m][k];
+            coef[e] = code.matValue[m][k];
+        }
+    ems_code_desc desc = {code.N, code.M, code.GF, code.logGF, code.nbBranch, code.rowDegree, col, coef};
+    ems_params prm = {nbMax, NbOper, offset, NbIterMax, 1};
+    ems_handle *h = NULL;
+    int rc = ems_create(&h, &desc, &prm, batch, device);
+    if (rc) die("ems_create", rc);
+
+    char note[40] = "FB30";
+    char file_name[128];
+    printf("\n\t Note             : %s\n", note);
+    sprintf(file_name, "./data/results_N%d_CR%0.2f_GF%d_IT%d_Offset%0.1f_nm%d_%s.txt", code.N, code.rate, code.GF,
+            NbIterMax, offset, nbMax, note);
+    time_t now = time(NULL);
+    printf("Simulation started at time: %s \n", ctime(&now));
+
+    const int N = code.N, K = code.K, logGF = code.logGF;
+    int **NBIN = calloc(N, sizeof(int *)), **KBIN = calloc(K, sizeof(int *));
+    for (int n = 0; n < N; n++) NBIN[n] = calloc(logGF, sizeof(int));
+    for (int k = 0; k < K; k++) KBIN[k] = calloc(logGF, sizeof(int));
+    int *KSYMB = calloc(K, sizeof(int));
+    int *cw = malloc(sizeof(int) * (size_t)batch * N);
+    float *noisy = malloc(sizeof(float) * (size_t)batch * N * logGF);
+    int *decide = malloc(sizeof(int) * (size_t)batch * N);
+    int *iters = malloc(sizeof(int) * batch), *synd = malloc(sizeof(int) * batch), *nberr = malloc(sizeof(int) * batch);
+
+    int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
+    double t_decode = 0;
+    while (nb < NbMonteCarlo && !stop) {
+        const int B = (NbMonteCarlo - nb) < batch ? (NbMonteCarlo - nb) : batch;
+        float sigma = 0;
+        for (int b = 0; b < B; b++) {                                   /* NB_LDPC.c:255-261 draw order */
+            RandomBinaryGenerator(N, code.M, code.GF, logGF, KBIN, KSYMB, table.BINGF, &Idum);
+            Encoding(&code, &table, cw + (size_t)b * N, NBIN, KSYMB);
+            sigma = ems_awgn_bpsk_noise(&code, NBIN, EbN, &Idum, noisy + (size_t)b * N * logGF);
+        }
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if ((rc = ems_decode_batch(h, noisy, sigma, B, decide, iters, synd))) die("ems_decode_batch", rc);
+        if ((rc = ems_count_errors(h, cw, B, nberr))) die("ems_count_errors", rc);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        t_decode += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        for (int b = 0; b < B; b++) {                                   /* NB_LDPC.c:474-507, frame order */
+            nb++;
+            sum_it += iters[b];
+            total_errors += nberr[b];
+            if (nberr[b] != 0) {
+                nbErroneousFrames++;
+                if (synd[b] == 0) nbUndetectedErrors++;
+            }
+            printf("\r<%d> FER= %d / %d = %f BER= %d / x = %f  avr_it=%.2f", nbUndetectedErrors, nbErroneousFrames, nb,
+                   (double)nbErroneousFrames / nb, total_errors, (double)total_errors / ((double)nb * K * logGF),
+                   (double)sum_it / nb);
+            fflush(stdout);
+            if (nbErroneousFrames == 40) { stop = 1; break; }
+        }
+    }
+    /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
+    const int nb_logged = stop ? nb : nb + 1;
+    printf(" \n results are printed in file %s \n", file_name);
+    now = time(NULL);
+    char *ts = ctime(&now);
+    FILE *op = fopen(file_name, "a");
+    if (!op) {
+        printf(" \n !! file not found \n ");
+    } else {
+        fprintf(op, " SNR:%.2f: \t FER= %d / %d = %f ", EbN, nbErroneousFrames, nb_logged, (double)nbErroneousFrames / nb_logged);
+        fprintf(op, " \t BER= %d / x = \t %f  avr_it= \t %.2f \t time: %s", total_errors,
+                (double)total_errors / ((double)nb_logged * K * logGF), (double)sum_it / nb_logged, ts);
+        fclose(op);
+    }
+    printf(" \n results printed \n ");
+    printf("\n");
+    printf("Simulation complete at time: %s", ts);
+    fprintf(stderr, "[ems_sim] %d frames, GPU decode wall %.3f s (%.1f frames/s incl. PCIe), batch %d\n", nb, t_decode,
+            t_decode > 0 ? nb / t_decode : 0.0, batch);
+
+    ems_destroy(h);
+    free(col); free(coef); free(cw); free(noisy); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
+    for (int n = 0; n < N; n++) free(NBIN[n]);
+    for (int k = 0; k < K; k++) free(KBIN[k]);
+    free(NBIN); free(KBIN);
+    FreeCode(&code);
+    FreeTable(&table);
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,444 @@
+// ref_api.cpp -- the reference simulator's C boundary (include/nbldpc_ref_api.h) on top of the batched
+// GPU library.  Host-side pieces (loader, tables, allocators, RNG, encoder) are plain C++ because the
+// reference keeps them on the harness side; every hot-path symbol forwards to the HIP kernels through
+// the C ABI of ems_abi.h and never computes on the CPU.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ems_abi.h"
+#include "../../include/nbldpc_ref_api.h"
+
+namespace {
+
+// One GPU decoder context per code_t the caller has shown us (created lazily, destroyed by FreeCode).
+struct Ctx {
+    ems_handle *h = nullptr;
+    ems_params prm{};
+    int max_batch = 1;
+};
+std::map<const code_t *, Ctx> g_ctx;
+std::mutex g_mu;
+
+int env_device()
+{
+    const char *e = getenv("EMS_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+void complain(const char *who, int rc)
+{
+    fprintf(stderr, "\n[libems_hip] %s failed (%d): %s\n", who, rc, ems_last_error());
+}
+
+// row-pointer-over-one-block 2-D array, the allocation shape of init.c:310-415
+template <typename T> T **alloc2d(size_t rows, size_t cols)
+{
+    T **p = (T **)calloc(rows ? rows : 1, sizeof(T *));
+    T *blk = (T *)calloc((rows * cols) ? rows * cols : 1, sizeof(T));
+    for (size_t r = 0; r < rows; ++r) p[r] = blk + r * cols;
+    if (!rows) p[0] = blk;
+    return p;
+}
+template <typename T> void free2d(T **p)
+{
+    if (!p) return;
+    free(p[0]);
+    free(p);
+}
+
+void flatten(const code_t *code, std::vector<int> &col, std::vector<int> &coef, ems_code_desc &d)
+{
+    col.clear();
+    coef.clear();
+    for (int m = 0; m < code->M; ++m)
+        for (int k = 0; k < code->rowDegree[m]; ++k) {
+            col.push_back(code->mat[m][k]);
+            coef.push_back(code->matValue[m][k]);
+        }
+    d.N = code->N; d.M = code->M; d.GF = code->GF; d.logGF = code->logGF;
+    d.nbBranch = (int)col.size();
+    d.rowDegree = code->rowDegree; d.col = col.data(); d.coef = coef.data();
+}
+
+// Fetch (or build) the GPU context of `code` for message length nm.
+int get_ctx(const code_t *code, int nm, int NbIterMax, int NbOper, float offset, Ctx **out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx &c = g_ctx[code];
+    ems_params p{nm, NbOper, offset, NbIterMax, 1};
+    if (c.h && c.prm.nm != nm) {
+        ems_destroy(c.h);
+        c.h = nullptr;
+    }
+    if (!c.h) {
+        std::vector<int> col, coef;
+        ems_code_desc d;
+        flatten(code, col, coef, d);
+        int rc = ems_create(&c.h, &d, &p, c.max_batch, env_device());
+        if (rc) { g_ctx.erase(code); return rc; }
+    } else {
+        int rc = ems_set_params(c.h, &p);
+        if (rc) return rc;
+    }
+    c.prm = p;
+    *out = &c;
+    return EMS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------
+// field tables (init.c:37-130, :427-526)
+// ---------------------------------------------------------------------------------------------------
+void Table_Add_GF(table_t *table, int GF, int logGF)   /* init.c:37: XOR of binary images */
+{
+    std::vector<int> img(GF), inv(GF);
+    for (int g = 0; g < GF; ++g) {
+        int b = 0;
+        for (int l = 0; l < logGF; ++l) b |= (table->BINGF[g][l] & 1) << l;
+        img[g] = b;
+        inv[b] = g;
+    }
+    for (int a = 0; a < GF; ++a)
+        for (int b = 0; b < GF; ++b) table->ADDGF[a][b] = inv[img[a] ^ img[b]];
+}
+
+void Table_Mul_GF(int **MULGF, int GF)                  /* init.c:65: exponents add modulo GF-1 */
+{
+    for (int a = 0; a < GF; ++a)
+        for (int b = 0; b < GF; ++b) MULGF[a][b] = (a && b) ? (a + b - 2) % (GF - 1) + 1 : 0;
+}
+
+void Table_Div_GF(int **DIVGF, int GF)                  /* init.c:100: -1 on division by zero */
+{
+    for (int a = 0; a < GF; ++a)
+        for (int b = 0; b < GF; ++b) {
+            if (b == 0) DIVGF[a][b] = -1;
+            else if (a == 0) DIVGF[a][b] = 0;
+            else DIVGF[a][b] = ((a - b) % (GF - 1) + (GF - 1)) % (GF - 1) + 1;
+        }
+}
+
+void LoadTables(table_t *table, int GF, int logGF)      /* init.c:427 */
+{
+    uint8_t i2b[256], b2i[256];
+    if (ems_gf_tables(GF, i2b, b2i) != EMS_OK) {
+        // the reference prints and exit()s here (init.c:431-435)
+        printf("The binary image of GF(%d) is not available in this version of the program. Please try GF(64) or GF(256)\n", GF);
+        exit(EXIT_FAILURE);
+    }
+    table->BINGF = alloc2d<int>(GF, logGF);
+    table->ADDGF = alloc2d<int>(GF, GF);
+    table->MULGF = alloc2d<int>(GF, GF);
+    table->DIVGF = alloc2d<int>(GF, GF);
+    for (int g = 0; g < GF; ++g)
+        for (int l = 0; l < logGF; ++l) table->BINGF[g][l] = (i2b[g] >> l) & 1;
+    Table_Add_GF(table, GF, logGF);
+    Table_Mul_GF(table->MULGF, GF);
+    Table_Div_GF(table->DIVGF, GF);
+}
+
+void FreeTable(table_t *table)                          /* init.c:515 */
+{
+    free2d(table->ADDGF); free2d(table->MULGF); free2d(table->DIVGF); free2d(table->BINGF);
+    table->ADDGF = table->MULGF = table->DIVGF = table->BINGF = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// code + decoder storage (init.c:143-415)
+// ---------------------------------------------------------------------------------------------------
+void LoadCode(char *FileMatrix, code_t *code)           /* init.c:143, both alist layouts */
+{
+    ems_code_desc d;
+    int rc = ems_load_code_file(FileMatrix, 0, &d);
+    if (rc) {
+        complain("LoadCode", rc);
+        exit(EXIT_FAILURE);
+    }
+    memset(code, 0, sizeof *code);
+    code->N = d.N; code->M = d.M; code->K = d.N - d.M; code->GF = d.GF; code->logGF = d.logGF;
+    code->rate = (float)(d.N - d.M) / d.N;
+    code->nbBranch = d.nbBranch;
+    code->rowDegree = (int *)calloc(d.M, sizeof(int));
+    code->columnDegree = (int *)calloc(d.N, sizeof(int));
+    code->mat = (int **)calloc(d.M, sizeof(int *));
+    code->matValue = (int **)calloc(d.M, sizeof(int *));
+    int e = 0;
+    for (int m = 0; m < d.M; ++m) {
+        const int dg = d.rowDegree[m];
+        code->rowDegree[m] = dg;
+        code->mat[m] = (int *)calloc(dg, sizeof(int));      // per-row blocks, as init.c:181-190
+        code->matValue[m] = (int *)calloc(dg, sizeof(int));
+        for (int k = 0; k < dg; ++k, ++e) {
+            code->mat[m][k] = d.col[e];
+            code->matValue[m][k] = d.coef[e];
+            code->columnDegree[d.col[e]]++;
+        }
+    }
+    ems_free_code_desc(&d);
+    printf("LDPC code parameters: \n");
+    printf(" \t N \t:%d \n \t K \t:%d \n \t M\t:%d \n \t CR\t:%g \n \t GF \t:%d \n \t logGF \t:%d\n", code->N, code->K,
+           code->M, code->rate, code->GF, code->logGF);
+    fflush(stdout);
+}
+
+void FreeCode(code_t *code)                             /* init.c:289 */
+{
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(code);
+        if (it != g_ctx.end()) {
+            if (it->second.h) ems_destroy(it->second.h);
+            g_ctx.erase(it);
+        }
+    }
+    for (int m = 0; m < code->M; ++m) {
+        free(code->mat[m]);
+        free(code->matValue[m]);
+    }
+    if (code->matUT) { free(code->matUT[0]); free(code->matUT); }
+    free(code->mat); free(code->matValue); free(code->rowDegree); free(code->columnDegree); free(code->Perm);
+    memset(code, 0, sizeof *code);
+}
+
+void AllocateDecoder(code_t *code, decoder_t *decoder)  /* init.c:310; decoder->nbMax set by caller */
+{
+    const int dc0 = code->rowDegree[0];                 // scratch sized by the first row (init.c:320)
+    decoder->nbBranch = code->nbBranch;
+    decoder->N = code->N;
+    decoder->CtoV = alloc2d<softdata_t>(code->nbBranch, code->GF);
+    decoder->M_CtoV_LLR = alloc2d<softdata_t>(dc0, code->GF);
+    decoder->M_VtoC_LLR = alloc2d<softdata_t>(dc0, decoder->nbMax);
+    decoder->M_CtoV_GF = alloc2d<int>(dc0, code->GF);
+    decoder->M_VtoC_GF = alloc2d<int>(dc0, decoder->nbMax);
+    decoder->APP = alloc2d<softdata_t>(code->N, code->GF);
+    decoder->intrinsic_LLR = alloc2d<softdata_t>(code->N, code->GF);
+    decoder->intrinsic_GF = alloc2d<int>(code->N, code->GF);
+}
+
+void FreeDecoder(decoder_t *decoder)                    /* init.c:395 */
+{
+    free2d(decoder->CtoV); free2d(decoder->M_CtoV_LLR); free2d(decoder->M_VtoC_LLR); free2d(decoder->M_CtoV_GF);
+    free2d(decoder->M_VtoC_GF); free2d(decoder->APP); free2d(decoder->intrinsic_LLR); free2d(decoder->intrinsic_GF);
+    memset(decoder, 0, sizeof *decoder);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RNG, source, encoder (tools.c:40-268) -- harness side, host
+// ---------------------------------------------------------------------------------------------------
+float My_drand48(int *initialise)                       /* tools.c:40, the __linux__ branch */
+{
+    (void)initialise;
+    return (float)drand48();
+}
+
+int Bin2GF(int *U, int GF, int logGF, int **BINGF)      /* tools.c:95 */
+{
+    for (int k = 0; k < GF; ++k) {
+        int l = 0;
+        while (l < logGF && U[l] == BINGF[k][l]) ++l;
+        if (l == logGF) return k;
+    }
+    return GF;
+}
+
+void RandomBinaryGenerator(int N, int M, int GF, int logGF, int **KBIN, int *KSYMB, int **BINGF, int *init_rand)
+{                                                       /* tools.c:124 */
+    for (int k = 0; k < N - M; ++k) {
+        for (int l = 0; l < logGF; ++l) KBIN[k][l] = (int)floor(My_drand48(init_rand) * 1.9999);
+        KSYMB[k] = Bin2GF(KBIN[k], GF, logGF, BINGF);
+    }
+}
+
+void GaussianElimination(code_t *code, table_t *table)  /* tools.c:151 */
+{
+    const int N = code->N, M = code->M;
+    code->matUT = alloc2d<int>(M, N);
+    code->Perm = (int *)calloc(N, sizeof(int));
+    for (int n = 0; n < N; ++n) code->Perm[n] = n;
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < code->rowDegree[m]; ++k) code->matUT[m][code->mat[m][k]] = code->matValue[m][k];
+    for (int m = 0; m < M; ++m) {
+        int *pr = code->matUT[m];
+        int piv = m;
+        while (piv < N && pr[piv] == 0) ++piv;
+        if (piv == N) {
+            printf("The matrix is not full rank (%d,%d)\n", m, piv);
+            exit(EXIT_FAILURE);
+        }
+        std::swap(code->Perm[piv], code->Perm[m]);
+        for (int r = 0; r < M; ++r) std::swap(code->matUT[r][m], code->matUT[r][piv]);
+        const int d = pr[m];
+        for (int r = m + 1; r < M; ++r) {
+            int *row = code->matUT[r];
+            const int lead = row[m];
+            if (!lead) continue;
+            // row <- (row / lead) * d + pivot_row over GF(q)
+            for (int n = m; n < N; ++n) {
+                int x = row[n];
+                if (x) x = table->MULGF[table->DIVGF[x][lead]][d];
+                row[n] = table->ADDGF[x][pr[n]];
+            }
+        }
+    }
+}
+
+int Encoding(code_t *code, table_t *table, int *CodeWord, int **NBIN, int *KSYMB)  /* tools.c:232 */
+{
+    const int N = code->N, M = code->M;
+    std::vector<int> sym(N);
+    for (int k = 0; k < N - M; ++k) sym[M + k] = KSYMB[k];
+    for (int m = M - 1; m >= 0; --m) {
+        const int *row = code->matUT[m];
+        int acc = 0;
+        for (int n = m + 1; n < N; ++n)
+            if (row[n]) acc = table->ADDGF[acc][table->MULGF[row[n]][sym[n]]];
+        sym[m] = table->DIVGF[acc][row[m]];
+    }
+    for (int n = 0; n < N; ++n) CodeWord[code->Perm[n]] = sym[n];
+    for (int n = 0; n < N; ++n)
+        for (int l = 0; l < code->logGF; ++l) NBIN[n][l] = table->BINGF[CodeWord[n]][l];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// channel (channel.c:38-98): noise on the host (same drand48 stream), LLR + sort on the GPU
+// ---------------------------------------------------------------------------------------------------
+float ems_awgn_bpsk_noise(code_t *code, int **NBIN, float EbN, int *init_rand, float *noisy)
+{
+    const double PI = 3.1415926536;                                            /* channel.c:18 */
+    const float sigma = (float)sqrt(1.0 / (2.0 * (double)code->rate * pow(10.0, (double)EbN / 10.0))); /* channel.c:51 */
+    for (int n = 0; n < code->N; ++n)
+        for (int l = 0; l < code->logGF; ++l) {
+            const float u = My_drand48(init_rand);
+            const float v = My_drand48(init_rand);
+            noisy[(size_t)n * code->logGF + l] = (float)((double)(1 - 2 * NBIN[n][l]) + (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * PI * (double)v));
+        }
+    return sigma;
+}
+
+void ModelChannel_AWGN_BPSK(code_t *code, decoder_t *decoder, table_t *table, int **NBIN, float EbN, int *init_rand)
+{
+    (void)table;
+    std::vector<float> noisy((size_t)code->N * code->logGF);
+    const float sigma = ems_awgn_bpsk_noise(code, NBIN, EbN, init_rand, noisy.data());
+    Ctx *c = nullptr;
+    int rc = get_ctx(code, decoder->nbMax, 2, 2 * decoder->nbMax, 0.f, &c);
+    if (!rc) rc = ems_llr_init(c->h, noisy.data(), sigma, 1);
+    if (!rc) rc = ems_get_sorted_llr(c->h, 0, decoder->intrinsic_LLR[0], decoder->intrinsic_GF[0]);
+    if (rc) {
+        complain("ModelChannel_AWGN_BPSK", rc);
+        exit(EXIT_FAILURE); // void signature: no way to report; never continue on stale LLRs
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// check node, decision, syndrome: device-backed single-node calls
+// ---------------------------------------------------------------------------------------------------
+int maximum(float *Y, int nl)                           /* bubble_decoder.c:18 */
+{
+    float best = 0.0f;
+    int pos = 0;
+    for (int i = 0; i < nl; ++i)
+        if (Y[i] > best) { best = Y[i]; pos = i; }
+    return pos;
+}
+
+int minimum(float *Y, int nl)                           /* bubble_decoder.c:38 */
+{
+    float best = 1e5f;
+    int pos = 0;
+    for (int i = 0; i < nl; ++i)
+        if (Y[i] < best) { best = Y[i]; pos = i; }
+    return pos;
+}
+
+int ElementaryStep(float *Input1, float *Input2, int *IndiceInput1, int *IndiceInput2, float *Output, int *IndiceOut,
+                   int **ADDGF, int GF, int nbMax, int nbOper)
+{
+    (void)ADDGF; // GF addition is an XOR of binary images on the device
+    int rc = ems_elementary_step(GF, nbMax, nbOper, Input1, Input2, IndiceInput1, IndiceInput2, Output, IndiceOut, env_device());
+    if (rc) complain("ElementaryStep", rc);
+    return rc; // the reference always returns 0 (bubble_decoder.c:592)
+}
+
+void CheckPassLogEMS(int node, decoder_t *decoder, code_t *code, table_t *table, int NbOper, float offset)
+{
+    const int dc = code->rowDegree[node], nm = decoder->nbMax, GF = code->GF;
+    int rc = ems_check_node(GF, dc, nm, NbOper, offset, code->matValue[node], decoder->M_VtoC_LLR[0], decoder->M_VtoC_GF[0],
+                            decoder->M_CtoV_LLR[0], env_device());
+    if (rc) {
+        complain("CheckPassLogEMS", rc);
+        exit(EXIT_FAILURE);
+    }
+    // visible side effects of the reference: inputs left rotated (:133-152), output symbols = identity (:274-278)
+    for (int t = 0; t < dc; ++t) {
+        for (int k = 0; k < nm; ++k)
+            if (decoder->M_VtoC_GF[t][k] != -1) decoder->M_VtoC_GF[t][k] = table->MULGF[decoder->M_VtoC_GF[t][k]][code->matValue[node][t]];
+        for (int g = 0; g < GF; ++g) decoder->M_CtoV_GF[t][g] = g;
+    }
+}
+
+void Decision(int *decision, float **APP, int N, int GF)    /* tools.c:312 */
+{
+    std::vector<float> flat((size_t)N * GF);
+    for (int n = 0; n < N; ++n) memcpy(&flat[(size_t)n * GF], APP[n], sizeof(float) * GF);
+    int rc = ems_decision(GF, N, flat.data(), decision, env_device());
+    if (rc) {
+        complain("Decision", rc);
+        exit(EXIT_FAILURE);
+    }
+}
+
+int Syndrom(code_t *code, int *decide, table_t *tableGF)    /* tools.c:284 */
+{
+    (void)tableGF;
+    std::vector<int> col, coef;
+    ems_code_desc d;
+    flatten(code, col, coef, d);
+    int synd = 0;
+    int rc = ems_syndrome(&d, decide, &synd, env_device());
+    if (rc) {
+        complain("Syndrom", rc);
+        exit(EXIT_FAILURE);
+    }
+    return synd;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decoding(): NB_LDPC.c:266-472 hoisted; one frame through the batched GPU path
+// ---------------------------------------------------------------------------------------------------
+int Decoding(code_t *code, table_t *table, decoder_t *decoder, int NbIterMax, int NbOper, float offset, int *decide, int *synd)
+{
+    (void)table;
+    Ctx *c = nullptr;
+    int rc = get_ctx(code, decoder->nbMax, NbIterMax, NbOper, offset, &c);
+    if (rc) { complain("Decoding", rc); return rc; }
+    const int N = code->N, GF = code->GF;
+    // NB_LDPC.c:281-288: APP[n][intrinsic_GF[n][k]] = intrinsic_LLR[n][k]
+    std::vector<float> llr((size_t)N * GF, 1e5f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < GF; ++k) {
+            const int g = decoder->intrinsic_GF[n][k];
+            if (g >= 0 && g < GF) llr[(size_t)n * GF + g] = decoder->intrinsic_LLR[n][k];
+        }
+    int iters = 0, s = 0;
+    if ((rc = ems_load_llr(c->h, llr.data(), 1)) || (rc = ems_decode(c->h, 1)) ||
+        (rc = ems_get_results(c->h, 1, decide, &iters, &s)) || (rc = ems_get_app(c->h, 0, decoder->APP[0])) ||
+        (rc = ems_get_ctov(c->h, 0, decoder->CtoV[0]))) {
+        complain("Decoding", rc);
+        return rc;
+    }
+    if (synd) *synd = s;
+    return iters;
+}
+
+} // extern "C"

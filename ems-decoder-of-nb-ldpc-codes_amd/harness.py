@@ -1,0 +1,173 @@
+"""Batched / multi-GPU Monte-Carlo driver around the GPU decoder.
+
+Mirrors the reference's main() loop (NB_LDPC.c:250-507) for N processes, one per GPU:
+  * frames are independent, so the global frame index f (1-based as in NB_LDPC.c:250) is sharded in
+    contiguous batches: batch j = frames [j*B, (j+1)*B) goes to rank j mod R;
+  * every rank positions the drand48 stream by LCG jump-ahead to draw offset
+    (f-1) * (K*logGF + 2*N*logGF), so each frame sees exactly the uniforms the single-process reference
+    would have drawn for it (source -> encoder -> channel order, NB_LDPC.c:255-261);
+  * there is no data-path collective; per round the ranks exchange only counters:
+    one all-reduce(sum) of {frames, erroneous frames, bit errors, undetected, sum of iterations}
+    (5 x int64) drives the global ">= 40 erroneous frames" stop, and an all-gather of the per-frame
+    (bit errors, syndrome, iterations) triples (12 B/frame) lets rank 0 print the reference's progress
+    line in frame order and truncate at precisely the 40th erroneous frame (NB_LDPC.c:506).
+Collectives go through torch.distributed (backend "nccl" == RCCL over xGMI on the GPU node, "gloo" in
+the CPU tests); without an initialised process group everything degenerates to one rank.
+"""
+import numpy as np
+
+from . import Code, Decoder
+from .refapi import RefSession, seed48
+
+LCG_A = 0x5DEECE66D
+LCG_C = 0xB
+LCG_MASK = (1 << 48) - 1
+
+
+def lcg_jump(x0, n):
+    """State of glibc's drand48 LCG after n draws from state x0 (affine map raised to the n-th power)."""
+    a, c = 1, 0            # identity map x -> a*x + c
+    ba, bc = LCG_A, LCG_C  # one step
+    while n > 0:
+        if n & 1:
+            a, c = (ba * a) & LCG_MASK, (ba * c + bc) & LCG_MASK
+        ba, bc = (ba * ba) & LCG_MASK, (ba * bc + bc) & LCG_MASK
+        n >>= 1
+    return (a * x0 + c) & LCG_MASK
+
+
+def draws_per_frame(K, N, logGF):
+    """K*logGF source bits (tools.c:124) + 2 uniforms per transmitted bit (channel.c:56-57)."""
+    return K * logGF + 2 * N * logGF
+
+
+def batch_of_rank(round_idx, rank, world, batch, n_frames):
+    """(first frame index 0-based, count) of the batch `rank` decodes in `round_idx`; count may be 0."""
+    j = round_idx * world + rank
+    start = j * batch
+    return start, max(0, min(batch, n_frames - start))
+
+
+class FrameSource:
+    """Draws frames exactly as the reference harness does, from any starting frame index."""
+
+    def __init__(self, matrix, nbMax):
+        self.s = RefSession(matrix, nbMax, need_encoder=True)
+        self.dpf = draws_per_frame(self.s.K, self.s.N, self.s.logGF)
+
+    def position(self, frame0):
+        seed48(lcg_jump(0, frame0 * self.dpf))
+
+    def draw(self, count, EbN):
+        cws = np.zeros((count, self.s.N), np.int32)
+        noisy = np.zeros((count, self.s.N, self.s.logGF), np.float32)
+        sigma = 0.0
+        for b in range(count):
+            cws[b] = self.s.draw_codeword()
+            sigma, noisy[b] = self.s.noise(EbN)
+        return cws, noisy, sigma
+
+    def close(self):
+        self.s.close()
+
+
+class Counters:
+    """The reference's running totals (NB_LDPC.c:73-74,186) and its progress line (:498)."""
+
+    def __init__(self, K, logGF):
+        self.K, self.logGF = K, logGF
+        self.nb = self.err_frames = self.bit_errors = self.undetected = self.sum_it = 0
+        self.trace = []
+
+    def add(self, nberr, synd, iters):
+        self.nb += 1
+        self.sum_it += int(iters)
+        self.bit_errors += int(nberr)
+        if nberr != 0:
+            self.err_frames += 1
+            if synd == 0:
+                self.undetected += 1
+        self.trace.append((self.err_frames, self.bit_errors, "%.2f" % (self.sum_it / self.nb)))
+
+    def line(self):
+        return "<%d> FER= %d / %d = %f BER= %d / x = %f  avr_it=%.2f" % (
+            self.undetected, self.err_frames, self.nb, self.err_frames / self.nb, self.bit_errors,
+            self.bit_errors / (self.nb * self.K * self.logGF), self.sum_it / self.nb)
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=64, device=0, decode_fn=None,
+                max_err_frames=40, tensor_device="cpu", verbose=False):
+    """Run the Monte-Carlo loop over all ranks of the current process group (or one process).
+
+    decode_fn(noisy, sigma, cws) -> (nberr[B], synd[B], iters[B]); default = the GPU decoder.  The CPU
+    tests inject a stand-in so the sharding / reduction / ordering logic runs without a GPU.
+    Returns (Counters on every rank -- identical everywhere --, number of decode rounds)."""
+    import torch
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    src = FrameSource(matrix, nm)
+    dec = None
+    if decode_fn is None:
+        code = Code(matrix)
+        dec = Decoder(code, nm, NbOper, offset, NbIterMax, max_batch=batch, device=device)
+
+        def decode_fn(noisy, sigma, cws):
+            _d, iters, synd = dec.decode_batch(noisy, sigma)
+            return dec.count_errors(cws), synd, iters
+
+    cnt = Counters(src.s.K, src.s.logGF)
+    rounds = 0
+    stop = False
+    n_rounds = -(-NbMonteCarlo // (batch * world))
+    for r in range(n_rounds):
+        start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
+        triples = np.full((batch, 3), -1, np.int64)
+        if count > 0:
+            src.position(start)
+            cws, noisy, sigma = src.draw(count, EbN)
+            nberr, synd, iters = decode_fn(noisy, sigma, cws)
+            triples[:count, 0], triples[:count, 1], triples[:count, 2] = nberr, synd, iters
+        local = np.array([count, int((triples[:count, 0] != 0).sum()), int(triples[:count, 0].sum()),
+                          int(((triples[:count, 0] != 0) & (triples[:count, 1] == 0)).sum()), int(triples[:count, 2].sum())],
+                         np.int64)
+        if dist:
+            t = torch.from_numpy(local).to(tensor_device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # the one collective of the data path
+            g = torch.from_numpy(triples).to(tensor_device)
+            gathered = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(gathered, g)                              # 12 B/frame, reporting only
+            all_tr = [x.cpu().numpy() for x in gathered]
+            round_err = int(t.cpu()[1])
+        else:
+            all_tr = [triples]
+            round_err = int(local[1])
+        rounds += 1
+        for rk in range(world):                                       # global frame order
+            _s, c = batch_of_rank(r, rk, world, batch, NbMonteCarlo)
+            for b in range(c):
+                cnt.add(*all_tr[rk][b])
+                if verbose and rank == 0:
+                    print("\r" + cnt.line(), end="", flush=True)
+                if cnt.err_frames == max_err_frames:                  # NB_LDPC.c:506
+                    stop = True
+                    break
+            if stop:
+                break
+        del round_err
+        if stop:
+            break
+    src.close()
+    if dec is not None:
+        dec.close()
+    return cnt, rounds

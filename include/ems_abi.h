@@ -92,9 +92,14 @@ int ems_count_errors(ems_handle *h, const int *codewords_host, int B, int *nb_er
 /* ---- introspection for parity tests ---- */
 int ems_get_app(ems_handle *h, int frame, float *app /*[N][GF]*/);   /* decoder_t.APP after decode      */
 int ems_get_ctov(ems_handle *h, int frame, float *ctov /*[E][GF]*/); /* decoder_t.CtoV, expanded dense */
+/* channel.c:78-91: the ascending (LLR, symbol) form of frame `frame`'s channel LLRs, as
+ * decoder_t.intrinsic_LLR / intrinsic_GF hold it ([N][GF] each); valid after ems_llr_init. */
+int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
 /* Level schedule of the layered sweep: check nodes grouped so that no two in a level share a variable
  * node; visiting levels in order reproduces the sequential order of NB_LDPC.c:320 exactly. */
 int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr /*[M+1] or NULL*/, int *order /*[M] or NULL*/);
+/* The same schedule computed on the host only (no device needed). */
+int ems_level_schedule(const ems_code_desc *code, int *n_levels, int *level_ptr /*[M+1] or NULL*/, int *order /*[M] or NULL*/);
 
 /* ---- single-node entry points on the device (unit parity of bubble_decoder.c) ---- */
 /* bubble_decoder.c:316 ElementaryStep: index-domain symbols, -1 = invalid, 1e5 = padding value. */

@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference, compiled by `make -C oracle ref` into
+oracle/_ref/).  Everything written here is DATA (inputs + expected outputs); no reference source text
+is stored.  Fixtures:
+
+  kat_traces.json   cumulative (erroneous frames, bit errors, avr_it) traces printed by the reference
+                    executable for the known-answer runs K1..K5 of SURVEY.md section 8(c)
+  tables.npz        BINGF / ADDGF / MULGF / DIVGF of LoadTables() for GF(16), GF(64), GF(256)
+  loader.npz        mat / matValue of LoadCode() for the N96 code through both on-disk layouts
+  es_cases.npz      ElementaryStep() input/output tuples (random, quantised to force ties, padded
+                    (1e5,-1) tails, every short-output case seen)
+  cn_cases.npz      CheckPassLogEMS() input/output tuples on the N96 GF(64) code
+  channel.npz       ModelChannel_AWGN_BPSK() outputs (drand48 state reset to 0) for frame 1 of the N96
+                    code and the first variable nodes of the GF(16)/GF(256) 64800-bit codes
+  traj_n96.npz      per-sweep APP / decisions / syndrome of K1 frames 1..3, produced with the
+                    reference's own CheckPassLogEMS/Decision/Syndrom/channel/encoder functions and a
+                    Python transcription of the inline glue of NB_LDPC.c:266-472
+  traj_big.npz      per-sweep hard decisions (u8) + CRC-32 of the APP block for frame 1 of the two
+                    64800-bit codes, produced by the oracle restatement (itself pinned by K3/K4)
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+
+REFM = "/root/reference/matrices/"
+libc = C.CDLL("libc.so.6")
+
+
+def reset_drand48():
+    libc.seed48((C.c_ushort * 3)(0, 0, 0))
+
+
+def as2d(pp, rows, cols, dtype):
+    return np.array([[pp[r][c] for c in range(cols)] for r in range(rows)], dtype=dtype)
+
+
+def load_ref(fmt, path, nm):
+    L = orc.ref_lib(fmt)
+    code, table, dec = orc.RefCode(), orc.RefTable(), orc.RefDecoder()
+    L.LoadCode(os.fsencode(path), C.byref(code))
+    L.LoadTables(C.byref(table), code.GF, code.logGF)
+    dec.nbMax = nm
+    L.AllocateDecoder(C.byref(code), C.byref(dec))
+    return L, code, table, dec
+
+
+def kat_traces():
+    cases = {
+        "K1": ("kn", "KN/N96_K48_GF64.txt", 12, 10, 2.0, 16, 0.3, 32),
+        "K1_ubs": ("ubs", "N96_K48_GF64", 12, 10, 2.0, 16, 0.3, 32),
+        "K2": ("kn", "KN/N96_K48_GF64.txt", 200, 10, 3.0, 16, 0.3, 32),
+        "K3": ("ubs", "Ahmed_64800_R34_GF16", 4, 30, 3.0, 8, 0.3, 16),
+        "K3b": ("ubs", "Ahmed_64800_R34_GF16", 1, 30, 0.0, 8, 0.3, 16),
+        "K4": ("ubs", "Ahmed_64800_R12_GF256", 4, 30, 1.6, 20, 0.3, 40),
+        "K4b": ("ubs", "Ahmed_64800_R12_GF256", 3, 30, 2.0, 20, 0.3, 40),
+        "K5": ("ubs", "Mat24_N192_M96", 300, 100, 1.75, 24, 1.0, 48),
+    }
+    out = {}
+    for k, (fmt, mat, nf, it, eb, nm, off, nop) in cases.items():
+        tr = orc.run_reference_binary(fmt, nf, it, REFM + mat, eb, nm, off, nop)
+        assert len(tr) == nf, (k, len(tr))
+        out[k] = {"matrix": os.path.basename(mat), "fmt": fmt, "frames": nf, "NbIterMax": it, "EbN": eb, "nm": nm,
+                  "offset": off, "NbOper": nop, "trace": tr}
+        print(k, tr[-1], flush=True)
+    json.dump(out, open(os.path.join(HERE, "kat_traces.json"), "w"), indent=0)
+
+
+def tables():
+    L = orc.ref_lib("ubs")
+    out = {}
+    for q, lq in ((16, 4), (64, 6), (256, 8)):
+        t = orc.RefTable()
+        L.LoadTables(C.byref(t), q, lq)
+        out["bin%d" % q] = as2d(t.BINGF, q, lq, np.uint8)
+        out["add%d" % q] = as2d(t.ADDGF, q, q, np.uint8)
+        out["mul%d" % q] = as2d(t.MULGF, q, q, np.uint8)
+        out["div%d" % q] = as2d(t.DIVGF, q, q, np.int16)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
+
+
+def loader():
+    out = {}
+    for tag, fmt, path in (("ubs", "ubs", REFM + "N96_K48_GF64"), ("kn", "kn", REFM + "KN/N96_K48_GF64.txt")):
+        L, code, _t, _d = load_ref(fmt, path, 16)
+        out[tag + "_mat"] = as2d(code.mat, code.M, 4, np.int32)
+        out[tag + "_val"] = as2d(code.matValue, code.M, 4, np.int32)
+    np.savez_compressed(os.path.join(HERE, "loader.npz"), **out)
+
+
+def rand_list(rs, q, nm, short, quant):
+    v = np.sort((rs.randint(0, 80, nm) * quant).astype(np.float32))
+    v[0] = 0
+    g = rs.permutation(q)[:nm].astype(np.int32)
+    if short:
+        v[nm - short:] = 1e5
+        g[nm - short:] = -1
+    return v, g
+
+
+def es_cases():
+    L = orc.ref_lib("ubs")
+    rows = []
+    for q, lq, nm in ((16, 4, 8), (64, 6, 16), (256, 8, 20), (64, 6, 12), (256, 8, 8)):
+        t = orc.RefTable()
+        L.LoadTables(C.byref(t), q, lq)
+        rs = np.random.RandomState(1000 + q + nm)
+        kept_short = 0
+        for it in range(400):
+            quant = [0.25, 1.0, 0.03125][it % 3]
+            a, ia = rand_list(rs, q, nm, rs.randint(0, 5) if it % 4 == 0 else 0, quant)
+            b, ib = rand_list(rs, q, nm, rs.randint(0, 5) if it % 6 == 0 else 0, quant)
+            nop = int(rs.choice([nm, nm + 2, (3 * nm) // 2, 2 * nm]))
+            out = np.zeros(nm, np.float32)
+            io = np.zeros(nm, np.int32)
+            a2, b2 = a.copy(), b.copy()
+            # silence the reference's "out of bounds" printf on padded inputs
+            L.ElementaryStep(a2.ctypes, b2.ctypes, ia.ctypes, ib.ctypes, out.ctypes, io.ctypes, t.ADDGF, q, nm, nop)
+            is_short = (io < 0).any()
+            if it < 60 or (is_short and kept_short < 40):
+                kept_short += int(is_short)
+                pad = 32 - nm
+                rows.append(np.concatenate([[q, nm, nop], np.pad(a, (0, pad)).view(np.int32), np.pad(b, (0, pad)).view(np.int32),
+                                            np.pad(ia, (0, pad)), np.pad(ib, (0, pad)), np.pad(out, (0, pad)).view(np.int32),
+                                            np.pad(io, (0, pad))]).astype(np.int32))
+    arr = np.stack(rows)
+    print("es cases", arr.shape, "short:", int(sum((r[3 + 5 * 32:3 + 5 * 32 + r[1]] < 0).any() for r in arr)))
+    np.savez_compressed(os.path.join(HERE, "es_cases.npz"), cases=arr)
+
+
+def cn_cases():
+    L, code, table, dec = load_ref("ubs", REFM + "N96_K48_GF64", 16)
+    nm, dc, q = 16, 4, 64
+    rs = np.random.RandomState(77)
+    vl_all, vg_all, node_all, nop_all, out_all = [], [], [], [], []
+    for it in range(96):
+        node = int(rs.randint(0, code.M))
+        nop = int(rs.choice([16, 24, 32]))
+        vl = np.zeros((dc, nm), np.float32)
+        vg = np.zeros((dc, nm), np.int32)
+        for t in range(dc):
+            vl[t], vg[t] = rand_list(rs, q, nm, 0, [0.25, 1.0, 0.03125][it % 3])
+        for t in range(dc):
+            for k in range(nm):
+                dec.M_VtoC_LLR[t][k] = float(vl[t, k])
+                dec.M_VtoC_GF[t][k] = int(vg[t, k])
+        L.CheckPassLogEMS(node, C.byref(dec), C.byref(code), C.byref(table), nop, C.c_float(0.3))
+        out = as2d(dec.M_CtoV_LLR, dc, q, np.float32)
+        vl_all.append(vl); vg_all.append(vg); node_all.append(node); nop_all.append(nop); out_all.append(out)
+    np.savez_compressed(os.path.join(HERE, "cn_cases.npz"), vl=np.stack(vl_all), vg=np.stack(vg_all),
+                        node=np.array(node_all, np.int32), nop=np.array(nop_all, np.int32), out=np.stack(out_all),
+                        offset=np.float32(0.3))
+
+
+def ref_frame(L, code, table, dec, EbN):
+    """One frame exactly as main() draws it (NB_LDPC.c:255-261) with the reference's own functions."""
+    N, K, lq = code.N, code.K, code.logGF
+    PI = C.POINTER(C.c_int)
+    NBIN = (PI * N)(*[C.cast((C.c_int * lq)(), PI) for _ in range(N)])
+    KBIN = (PI * K)(*[C.cast((C.c_int * lq)(), PI) for _ in range(K)])
+    KS = (C.c_int * K)()
+    CW = (C.c_int * N)()
+    idum = C.c_int(-1)
+    L.RandomBinaryGenerator(N, code.M, code.GF, lq, KBIN, KS, table.BINGF, C.byref(idum))
+    L.Encoding(C.byref(code), C.byref(table), CW, NBIN, KS)
+    L.ModelChannel_AWGN_BPSK(C.byref(code), C.byref(dec), C.byref(table), NBIN, C.c_float(EbN), C.byref(idum))
+    return np.array(CW[:], np.int32)
+
+
+def channel():
+    out = {}
+    for tag, fmt, path, nm, ebn, nkeep in (("n96", "ubs", REFM + "N96_K48_GF64", 16, 2.0, 16),
+                                           ("gf16", "ubs", REFM + "Ahmed_64800_R34_GF16", 8, 3.0, 64),
+                                           ("gf256", "ubs", REFM + "Ahmed_64800_R12_GF256", 20, 1.6, 24)):
+        L, code, table, dec = load_ref(fmt, path, nm)
+        L.GaussianElimination(C.byref(code), C.byref(table))
+        reset_drand48()
+        cw = ref_frame(L, code, table, dec, ebn)
+        q = code.GF
+        out[tag + "_cw"] = cw
+        out[tag + "_llr"] = as2d(dec.intrinsic_LLR, nkeep, q, np.float32)
+        out[tag + "_gf"] = as2d(dec.intrinsic_GF, nkeep, q, np.int16)
+        out[tag + "_ebn"] = np.float32(ebn)
+        print("channel", tag, cw[:6], flush=True)
+    np.savez_compressed(os.path.join(HERE, "channel.npz"), **out)
+
+
+def traj_n96():
+    """K1 frames 1..3: reference functions + a transcription of the inline decode glue."""
+    nm, nop, off, itmax, ebn = 16, 32, np.float32(0.3), 10, 2.0
+    L, code, table, dec = load_ref("kn", REFM + "KN/N96_K48_GF64.txt", nm)
+    L.GaussianElimination(C.byref(code), C.byref(table))
+    reset_drand48()
+    N, M, q, dc = code.N, code.M, code.GF, 4
+    mat = as2d(code.mat, M, dc, np.int32)
+    frames = []
+    for f in range(3):
+        cw = ref_frame(L, code, table, dec, ebn)
+        sl = as2d(dec.intrinsic_LLR, N, q, np.float32)
+        sg = as2d(dec.intrinsic_GF, N, q, np.int32)
+        app = np.zeros((N, q), np.float32)
+        for n in range(N):
+            app[n, sg[n]] = sl[n]
+        llr0 = app.copy()
+        ctov = np.zeros((M * dc, q), np.float32)
+        apps, decs, synds = [], [], []
+        dd = (C.c_int * N)()
+        for it in range(itmax - 1):
+            for node in range(M):
+                mvc = np.zeros((dc, q), np.float32)
+                for i in range(dc):
+                    mvc[i] = app[mat[node, i]] - ctov[node * dc + i]
+                    w = mvc[i].copy()
+                    for k in range(nm):
+                        g = int(np.argmin(w))           # first minimum == strict '<' scan
+                        v = w[g] if w[g] < np.float32(1e5) else np.float32(1e5)
+                        g = g if w[g] < np.float32(1e5) else 0
+                        dec.M_VtoC_LLR[i][k] = float(v)
+                        dec.M_VtoC_GF[i][k] = g
+                        w[g] = np.float32(1e5)
+                    v0 = np.float32(dec.M_VtoC_LLR[i][0])
+                    for k in range(1, nm):
+                        dec.M_VtoC_LLR[i][k] = float(np.float32(dec.M_VtoC_LLR[i][k]) - v0)
+                    dec.M_VtoC_LLR[i][0] = 0.0
+                L.CheckPassLogEMS(node, C.byref(dec), C.byref(code), C.byref(table), nop, C.c_float(off))
+                mcv = as2d(dec.M_CtoV_LLR, dc, q, np.float32)
+                for i in range(dc):
+                    ctov[node * dc + i] = mcv[i]
+                    app[mat[node, i]] = mcv[i] + mvc[i]
+            rows = (C.POINTER(C.c_float) * N)(*[app[n].ctypes.data_as(C.POINTER(C.c_float)) for n in range(N)])
+            L.Decision(dd, rows, N, q)
+            synd = L.Syndrom(C.byref(code), dd, C.byref(table))
+            apps.append(app.copy()); decs.append(np.array(dd[:], np.int32)); synds.append(synd)
+            if synd == 0:
+                break
+        frames.append((cw, llr0, np.stack(apps), np.stack(decs), np.array(synds, np.int32)))
+        print("traj frame", f + 1, "sweeps", len(synds), "synd", synds[-1], flush=True)
+    out = {}
+    for f, (cw, llr0, apps, decs, synds) in enumerate(frames):
+        out["f%d_cw" % f] = cw; out["f%d_llr" % f] = llr0; out["f%d_app" % f] = apps
+        out["f%d_dec" % f] = decs; out["f%d_synd" % f] = synds
+    np.savez_compressed(os.path.join(HERE, "traj_n96.npz"), **out)
+
+
+def traj_big():
+    out = {}
+    for tag, mat, nm, nop, ebn in (("gf16", "Ahmed_64800_R34_GF16", 8, 16, 3.0), ("gf256", "Ahmed_64800_R12_GF256", 20, 40, 1.6)):
+        o = orc.Oracle(REFM + mat)
+        rng = orc.Rng(0)
+        sigma = o.sigma(ebn)
+        cw, noisy = o.draw_frame(rng, sigma)
+        res = o.decode(o.llr(noisy, sigma), nm, nop, 0.3, 30, want_sweeps=True)
+        out[tag + "_cw"] = cw.astype(np.uint8)
+        out[tag + "_dec"] = res["sweep_decide"]
+        out[tag + "_crc"] = res["sweep_crc"]
+        out[tag + "_synd"] = res["sweep_synd"]
+        out[tag + "_iters"] = np.int32(res["iters"])
+        out[tag + "_ebn"] = np.float32(ebn)
+        print("traj_big", tag, res["iters"], res["synd"], flush=True)
+    np.savez_compressed(os.path.join(HERE, "traj_big.npz"), **out)
+
+
+if __name__ == "__main__":
+    orc.build()
+    assert orc.ref_available(), "build the reference first: make -C oracle ref"
+    todo = sys.argv[1:] or ["tables", "loader", "es", "cn", "channel", "traj_n96", "traj_big", "kat"]
+    for name in todo:
+        {"tables": tables, "loader": loader, "es": es_cases, "cn": cn_cases, "channel": channel,
+         "traj_n96": traj_n96, "traj_big": traj_big, "kat": kat_traces}[name]()

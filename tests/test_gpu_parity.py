@@ -1,0 +1,333 @@
+"""Parity tests proper (run on the MI355X with -m gpu): the HIP path, called through the C ABI, against
+the golden vectors generated from the reference and against the CPU oracle on the same seeded inputs.
+Bar: bit-exact for everything on the decode path (hard decisions, syndrome, iteration counts, APP and
+CtoV floats -- the path uses only f32 add/sub/compare, so the tolerance is 0 ulp); the channel LLR is
+also required bit-exact (tolerance 0: the kernel keeps the reference's float/double promotion order)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import MAT, FieldOracle, es_case_fields, gold
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------------------------
+# check-node level (bubble_decoder.c) through ElementaryStep / CheckPassLogEMS
+# ---------------------------------------------------------------------------------------------------
+def test_elementary_step_golden(pkg):
+    cases = gold("es_cases.npz")["cases"]
+    short = 0
+    for row in cases:
+        q, nm, nop, a, b, ia, ib, eo, eio = es_case_fields(row)
+        out, io = pkg.ElementaryStep(a, b, ia, ib, q, nm, nop)
+        assert out.tobytes() == eo.tobytes() and (io == eio).all()
+        short += int((eio < 0).any())
+    assert short >= 40
+
+
+def test_check_node_golden(pkg):
+    g = gold("cn_cases.npz")
+    code = pkg.Code(os.path.join(MAT, "N96_K48_GF64"))
+    coefs = code.coef.reshape(code.M, 4)
+    for vl, vg, node, nop, out in zip(g["vl"], g["vg"], g["node"], g["nop"], g["out"]):
+        got = pkg.CheckPassLogEMS(coefs[node], vl, vg, 64, int(nop), float(g["offset"]))
+        assert got.tobytes() == out.tobytes()
+
+
+@pytest.mark.parametrize("q,nm,dc", [(64, 16, 4), (256, 20, 4), (16, 8, 8), (64, 12, 3), (64, 12, 6), (256, 10, 5), (256, 32, 4),
+                                     (64, 8, 2), (16, 5, 4)])
+def test_check_node_random_vs_oracle(pkg, orc, q, nm, dc):
+    o = FieldOracle(orc, q)
+    rs = np.random.RandomState(q + nm + dc)
+    for it in range(30):
+        vl = np.zeros((dc, nm), np.float32)
+        vg = np.zeros((dc, nm), np.int32)
+        for t in range(dc):
+            vl[t] = np.sort((rs.randint(0, 60, nm) * [0.25, 1.0][it % 2]).astype(np.float32))
+            vl[t, 0] = 0
+            vg[t] = rs.permutation(q)[:nm]
+        coef = rs.randint(1, q, dc).astype(np.int32)
+        nop = int(rs.choice([nm, 2 * nm]))
+        assert pkg.CheckPassLogEMS(coef, vl, vg, q, nop, 0.3).tobytes() == o.check_node(coef, vl, vg, nop, 0.3).tobytes()
+
+
+def test_decision_and_syndrome_units(pkg, orc):
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")
+    o = orc.Oracle(path)
+    code = pkg.Code(path)
+    rs = np.random.RandomState(5)
+    app = (rs.randint(0, 50, (o.N, o.q)) * 0.5).astype(np.float32)     # many ties -> lowest symbol
+    app[7] = 2e5                                                       # nothing below 1e5 -> symbol 0
+    d = pkg.Decision(app)
+    assert (d == o.decision(app)).all() and d[7] == 0
+    assert pkg.Syndrom(code, d) == o.syndrome(d)
+    cw, _ = o.draw_frame(orc.Rng(0), 0.5)
+    assert pkg.Syndrom(code, cw) == 0
+    cw[100] ^= 3
+    assert pkg.Syndrom(code, cw) == o.syndrome(cw) != 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# channel LLR (channel.c:66-91)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,mat,nm", [("n96", "N96_K48_GF64", 16), ("gf16", "Ahmed_64800_R34_GF16", 8), ("gf256", "Ahmed_64800_R12_GF256", 20)])
+def test_channel_llr_golden(pkg, orc, tag, mat, nm):
+    g = gold("channel.npz")
+    path = os.path.join(MAT, mat)
+    o = orc.Oracle(path)
+    sigma = o.sigma(float(g[tag + "_ebn"]))
+    _cw, noisy = o.draw_frame(orc.Rng(0), sigma)       # host-side noise stays in the harness (drand48)
+    dec = pkg.Decoder(pkg.Code(path), nm, 2 * nm, 0.3, 10, max_batch=1)
+    dec.llr_init(noisy[None], sigma)
+    dec.synchronize()
+    assert dec.app(0).tobytes() == o.llr(noisy, sigma).tobytes()       # every LLR of the frame, 0 ulp
+    sl, sg = dec.sorted_llr(0)
+    n = g[tag + "_llr"].shape[0]
+    assert sl[:n].tobytes() == g[tag + "_llr"].tobytes() and (sg[:n] == g[tag + "_gf"]).all()
+    dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# frame decode (NB_LDPC.c:266-472)
+# ---------------------------------------------------------------------------------------------------
+def _decode_vs_oracle(pkg, orc, name, nm, nop, off, itmax, ebn, B, state=True, early_exit=True):
+    path = os.path.join(MAT, name)
+    o = orc.Oracle(path)
+    sigma = o.sigma(ebn)
+    rng = orc.Rng(0)
+    frames = [o.draw_frame(rng, sigma) for _ in range(B)]
+    noisy = np.stack([f[1] for f in frames])
+    cws = np.stack([f[0] for f in frames])
+    dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=B, early_exit=early_exit)
+    decide, iters, synd = dec.decode_batch(noisy, sigma)
+    nerr = dec.count_errors(cws)
+    for b in range(B):
+        ref = o.decode(o.llr(noisy[b], sigma), nm, nop, off, itmax, early_exit=early_exit, want_state=state)
+        assert (decide[b] == ref["decide"]).all(), "frame %d: hard decisions differ" % b
+        assert iters[b] == ref["iters"] and synd[b] == ref["synd"], "frame %d: iterations / syndrome differ" % b
+        assert nerr[b] == o.bit_errors(ref["decide"], cws[b])
+        if state:
+            assert dec.app(b).tobytes() == ref["app"].tobytes(), "frame %d: APP differs" % b
+            assert dec.ctov(b).tobytes() == ref["ctov"].tobytes(), "frame %d: CtoV differs" % b
+    dec.close()
+    return iters
+
+
+def test_decode_n96_vs_oracle(pkg, orc):
+    it = _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 10, 2.0, 96)
+    assert list(it[:3]) == [4, 10, 10]                 # K1 frames 1..3: 4 sweeps, then two non-converged
+
+
+def test_decode_n96_low_snr_fixed_work(pkg, orc):
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 32, early_exit=False)
+
+
+def test_decode_n96_other_parameters(pkg, orc):
+    _decode_vs_oracle(pkg, orc, "KN_N96_K48_GF64.txt", 12, 18, 1.0, 8, 1.0, 16)     # NbOper = 1.5 nm, offset 1
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 30, 45, 0.3, 5, 3.0, 8)             # start.sh parameters
+    _decode_vs_oracle(pkg, orc, "Mat24_N192_M96", 24, 48, 1.0, 20, 1.75, 24)        # NB_LDPC.c:55-57
+
+
+def test_decode_gf16_vs_oracle(pkg, orc):
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 4)
+    assert list(it) == [6, 5, 5, 5]                    # K3
+
+
+def test_decode_gf256_vs_oracle(pkg, orc):
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.6, 4)
+    assert list(it) == [30, 30, 30, 25]                # K4: frame 4 converges in 25 sweeps
+
+
+def test_trajectory_n96_golden(pkg, orc):
+    """Sweep-by-sweep APP of the reference-derived K1 trajectories: run the GPU for s sweeps, compare."""
+    g = gold("traj_n96.npz")
+    code = pkg.Code(os.path.join(MAT, "KN_N96_K48_GF64.txt"))
+    for f in range(3):
+        apps, decs, synds = g["f%d_app" % f], g["f%d_dec" % f], g["f%d_synd" % f]
+        for s in range(1, len(synds) + 1):
+            dec = pkg.Decoder(code, 16, 32, 0.3, s + 1, max_batch=1, early_exit=False)
+            dec.load_llr(g["f%d_llr" % f][None])
+            dec.decode(1)
+            d, _it, sy = dec.results(1)
+            assert dec.app(0).tobytes() == apps[s - 1].tobytes()
+            assert (d[0] == decs[s - 1]).all() and sy[0] == synds[s - 1]
+            dec.close()
+
+
+@pytest.mark.parametrize("tag,mat,nm,nop,sweeps", [("gf16", "Ahmed_64800_R34_GF16", 8, 16, (1, 3, 6)),
+                                                    ("gf256", "Ahmed_64800_R12_GF256", 20, 40, (1, 2, 10, 29))])
+def test_trajectory_big_golden(pkg, orc, tag, mat, nm, nop, sweeps):
+    g = gold("traj_big.npz")
+    path = os.path.join(MAT, mat)
+    o = orc.Oracle(path)
+    sigma = o.sigma(float(g[tag + "_ebn"]))
+    _cw, noisy = o.draw_frame(orc.Rng(0), sigma)
+    code = pkg.Code(path)
+    for s in sweeps:
+        if s > len(g[tag + "_crc"]):
+            continue
+        dec = pkg.Decoder(code, nm, nop, 0.3, s + 1, max_batch=1, early_exit=False)
+        d, _it, sy = dec.decode_batch(noisy[None], sigma)
+        assert orc.crc32(dec.app(0)) == int(g[tag + "_crc"][s - 1])
+        assert (d[0].astype(np.uint8) == g[tag + "_dec"][s - 1]).all() and sy[0] == int(g[tag + "_synd"][s - 1])
+        dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases the domain offers
+# ---------------------------------------------------------------------------------------------------
+def test_noiseless_frames_massive_ties(pkg, orc):
+    """y = +-1 exactly: only logGF+1 distinct LLR values per node (huge tie groups in the top-nm
+    selection, resolved by lowest symbol), decode must return the codeword after one sweep."""
+    for name, nm in (("N96_K48_GF64", 16), ("Ahmed_64800_R12_GF256", 20)):
+        path = os.path.join(MAT, name)
+        o = orc.Oracle(path)
+        rng = orc.Rng(0)
+        cw, _ = o.draw_frame(rng, 0.5)
+        bits = (o.idx2bin[cw][:, None] >> np.arange(o.logq)) & 1
+        noisy = (1.0 - 2.0 * bits).astype(np.float32)
+        dec = pkg.Decoder(pkg.Code(path), nm, 2 * nm, 0.3, 10, max_batch=1)
+        d, it, sy = dec.decode_batch(noisy[None], 0.7)
+        ref = o.decode(o.llr(noisy, 0.7), nm, 2 * nm, 0.3, 10, want_state=True)
+        assert (d[0] == cw).all() and it[0] == 1 and sy[0] == 0
+        assert (d[0] == ref["decide"]).all() and dec.app(0).tobytes() == ref["app"].tobytes()
+        dec.close()
+
+
+def test_saturated_and_negative_llrs(pkg, orc):
+    """LLR rows containing values >= 1e5 (never selectable, NB_LDPC.c:362) and negative values."""
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    rs = np.random.RandomState(11)
+    llr = (rs.rand(4, o.N, o.q) * 40).astype(np.float32)
+    llr[0, :, 20:] = 1e5            # fewer than nm selectable symbols
+    llr[1] -= 15.0                  # negative entries
+    llr[2, 3, :] = 2e5              # a node with nothing selectable
+    llr[3] = np.round(llr[3])       # ties
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 6, max_batch=4)
+    dec.load_llr(llr)
+    dec.decode(4)
+    d, it, sy = dec.results(4)
+    for b in range(4):
+        ref = o.decode(llr[b], 16, 32, 0.3, 6, want_state=True)
+        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"]
+        assert dec.app(b).tobytes() == ref["app"].tobytes()
+    dec.close()
+
+
+def test_batch_position_invariance_and_repeatability(pkg, orc):
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    sigma = o.sigma(1.5)
+    rng = orc.Rng(0)
+    noisy = np.stack([o.draw_frame(rng, sigma)[1] for _ in range(40)])
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 10, max_batch=40)
+    a = dec.decode_batch(noisy, sigma)
+    perm = np.random.RandomState(0).permutation(40)
+    b = dec.decode_batch(noisy[perm], sigma)
+    c = dec.decode_batch(noisy[:7], sigma)            # ragged: fewer frames than max_batch
+    for x, y in zip(a, b):
+        assert (x[perm] == y).all()
+    for x, y in zip(a, c):
+        assert (x[:7] == y).all()
+    dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_headline_batch256_properties(pkg, orc):
+    """Ahmed_64800_R12_GF256, nm=20, 30 iterations, batch 256: encode -> AWGN -> decode round trip at
+    high SNR recovers every codeword (zero syndrome, zero bit errors); duplicated frames decode
+    identically; two of the frames are checked in full against the oracle."""
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = orc.Oracle(path)
+    sigma = o.sigma(3.0)
+    rng = orc.Rng(0)
+    base = [o.draw_frame(rng, sigma) for _ in range(8)]
+    idx = np.arange(256) % 8
+    noisy = np.stack([base[i][1] for i in idx])
+    cws = np.stack([base[i][0] for i in idx])
+    dec = pkg.Decoder(pkg.Code(path), 20, 40, 0.3, 30, max_batch=256)
+    d, it, sy = dec.decode_batch(noisy, sigma)
+    assert (sy == 0).all() and (d == cws).all() and (dec.count_errors(cws) == 0).all()
+    for b in range(8, 256):
+        assert it[b] == it[b % 8]
+    for b in (0, 5):
+        ref = o.decode(o.llr(noisy[b], sigma), 20, 40, 0.3, 30)
+        assert it[b] == ref["iters"] and (d[b] == ref["decide"]).all()
+    dec.close()
+
+
+def test_full_size_n96_batch8192(pkg, orc):
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    sigma = o.sigma(2.0)
+    rng = orc.Rng(0)
+    fr = [o.draw_frame(rng, sigma) for _ in range(8192)]
+    noisy = np.stack([f[1] for f in fr])
+    cws = np.stack([f[0] for f in fr])
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 30, max_batch=8192)
+    d, it, sy = dec.decode_batch(noisy, sigma)
+    nerr = dec.count_errors(cws)
+    rec = o.sim(orc.Rng(0), 2.0, 16, 32, 0.3, 30, 8192)
+    assert (nerr == rec[:, 0]).all() and (sy == rec[:, 1]).all() and (it == rec[:, 2]).all()
+    dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference-shaped boundary and the C harness
+# ---------------------------------------------------------------------------------------------------
+def test_reference_shaped_api_frame_by_frame(pkg, orc, refapi):
+    """LoadCode ... ModelChannel_AWGN_BPSK -> Decoding() in the order main() calls them, vs the oracle."""
+    path = os.path.join(MAT, "N96_K48_GF64")
+    s = refapi.RefSession(path, 16)
+    o = orc.Oracle(path)
+    rng = orc.Rng(0)
+    refapi.seed48(0)
+    sg = o.sigma(2.0)
+    for f in range(6):
+        cw = s.draw_codeword()
+        sl, sgf = s.model_channel(2.0)
+        ocw, onoisy = o.draw_frame(rng, sg)
+        osl, osg = o.sort_llr(o.llr(onoisy, sg))
+        assert (cw == ocw).all() and sl.tobytes() == osl.tobytes() and (sgf == osg).all()
+        it, decide, synd = s.decoding(10, 32, 0.3)
+        ref = o.decode(o.llr(onoisy, sg), 16, 32, 0.3, 10, want_state=True)
+        assert it == ref["iters"] and synd == ref["synd"] and (decide == ref["decide"]).all()
+        assert s.APP.tobytes() == ref["app"].tobytes() and s.CtoV.tobytes() == ref["ctov"].tobytes()
+    s.close()
+
+
+def _run_ems_sim(pkg, args, batch, cwd):
+    os.makedirs(os.path.join(cwd, "data"), exist_ok=True)
+    out = subprocess.run([pkg.SIM_PATH] + [str(a) for a in args], cwd=cwd, env=dict(os.environ, EMS_BATCH=str(batch)),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    txt = out.stdout.decode("latin-1")
+    tr = [(int(m.group(1)), int(m.group(3)), m.group(4)) for m in
+          re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", txt)]
+    return tr
+
+
+@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128)])
+def test_c_harness_reproduces_reference_traces(pkg, kat, tmp_path, name, batch):
+    """The C Monte-Carlo harness (same argv as the reference) on the GPU prints the reference's trace."""
+    k = kat[name]
+    matrix = {"KN/N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    if name in ("K1", "K2"):
+        matrix = "KN_N96_K48_GF64.txt"
+    tr = _run_ems_sim(pkg, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]],
+                      batch, str(tmp_path))
+    assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
+
+
+def test_python_driver_single_rank_gpu(harness, kat):
+    k = kat["K2"]
+    cnt, _ = harness.monte_carlo(os.path.join(MAT, "KN_N96_K48_GF64.txt"), k["frames"], k["NbIterMax"], k["EbN"], k["nm"], k["offset"],
+                                 k["NbOper"], batch=32)
+    assert [list(t) for t in cnt.trace] == [list(t) for t in k["trace"]]

@@ -1,0 +1,137 @@
+"""The CPU oracle (oracle/ems_oracle.c) against the golden vectors generated from the REAL reference
+(tests/golden/make_golden.py).  Bit-exact everywhere: these pin the checker the GPU is judged by."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MAT, FieldOracle, es_case_fields, gold
+
+
+def test_gf_tables_match_reference(orc):
+    t = gold("tables.npz")
+    for q, lq in ((16, 4), (64, 6), (256, 8)):
+        o = FieldOracle(orc, q)
+        bits = t["bin%d" % q]
+        img = (bits.astype(np.int32) << np.arange(lq)).sum(1)
+        assert (o.idx2bin[:q] == img).all()
+        step = 1 if q < 256 else 5
+        for a in range(0, q, step):
+            for b in range(q):
+                assert o.add(a, b) == t["add%d" % q][a, b]
+                assert o.mul(a, b) == t["mul%d" % q][a, b]
+                assert o.div(a, b) == t["div%d" % q][a, b]
+    with pytest.raises(AssertionError):
+        FieldOracle(orc, 32)  # init.c:431: only 16/64/256
+
+
+def test_loader_both_layouts(orc):
+    g = gold("loader.npz")
+    for path, tag in ((os.path.join(MAT, "N96_K48_GF64"), "ubs"), (os.path.join(MAT, "KN_N96_K48_GF64.txt"), "kn")):
+        o = orc.Oracle(path)
+        assert (o.N, o.M, o.q, o.dc) == (16, 8, 64, 4)
+        assert (o.col.reshape(8, 4) == g[tag + "_mat"]).all()
+        assert (o.coef.reshape(8, 4) == g[tag + "_val"]).all()
+    assert (g["ubs_mat"] == g["kn_mat"]).all() and (g["ubs_val"] == g["kn_val"]).all()
+    assert list(g["ubs_mat"][0]) == [3, 6, 9, 15] and list(g["ubs_val"][0]) == [28, 2, 37, 50]
+
+
+def test_loader_rejects_garbage(orc, tmp_path):
+    p = tmp_path / "bad"
+    p.write_text("16 8 64\n2 2 2\n")
+    with pytest.raises(IOError):
+        orc.Oracle(str(p))
+    with pytest.raises(IOError):
+        orc.Oracle(str(tmp_path / "missing"))
+
+
+def test_elementary_step_golden(orc):
+    cases = gold("es_cases.npz")["cases"]
+    assert len(cases) >= 256
+    fo = {}
+    short = 0
+    for row in cases:
+        q, nm, nop, a, b, ia, ib, eo, eio = es_case_fields(row)
+        o = fo.setdefault(q, FieldOracle(orc, q))
+        out, io = o.elementary_step(a, b, ia, ib, nm, nop)
+        assert out.tobytes() == eo.tobytes() and (io == eio).all()
+        short += int((eio < 0).any())
+    assert short >= 40  # the rare short-output path is covered
+
+
+def test_check_node_golden(orc):
+    g = gold("cn_cases.npz")
+    o = orc.Oracle(os.path.join(MAT, "N96_K48_GF64"))
+    assert len(g["node"]) >= 64
+    for vl, vg, node, nop, out in zip(g["vl"], g["vg"], g["node"], g["nop"], g["out"]):
+        coef = o.coef[o.row_ptr[node]: o.row_ptr[node + 1]]
+        got = o.check_node(coef, vl, vg, int(nop), float(g["offset"]))
+        assert got.tobytes() == out.tobytes()
+
+
+@pytest.mark.parametrize("tag,mat", [("n96", "N96_K48_GF64"), ("gf16", "Ahmed_64800_R34_GF16"), ("gf256", "Ahmed_64800_R12_GF256")])
+def test_channel_golden(orc, tag, mat):
+    """Source + encoder + noise + LLR + sort vs ModelChannel_AWGN_BPSK of the reference (drand48 X0 = 0)."""
+    g = gold("channel.npz")
+    o = orc.Oracle(os.path.join(MAT, mat))
+    rng = orc.Rng(0)
+    sigma = o.sigma(float(g[tag + "_ebn"]))
+    cw, noisy = o.draw_frame(rng, sigma)
+    assert (cw == g[tag + "_cw"]).all()
+    n = g[tag + "_llr"].shape[0]
+    sl, sg = o.sort_llr(o.llr(noisy, sigma)[:n])
+    assert sl.tobytes() == g[tag + "_llr"].tobytes()
+    assert (sg == g[tag + "_gf"]).all()
+
+
+def test_rng_stream_head(orc):
+    r = orc.Rng(0)
+    L = orc.lib()
+    vals = [L.orc_drand48(orc.C.byref(r)) for _ in range(6)]
+    assert vals[0] == 11 * 2.0 ** -48
+    exp = [0.000985394698, 0.041631002, 0.176642641, 0.364602238, 0.0913306102]
+    assert np.allclose(vals[1:], exp, rtol=1e-8)
+
+
+def test_trajectory_n96_golden(orc):
+    """Per-sweep APP / decisions / syndrome of K1 frames 1..3 (reference functions + transcribed glue)."""
+    g = gold("traj_n96.npz")
+    o = orc.Oracle(os.path.join(MAT, "KN_N96_K48_GF64.txt"))
+    for f in range(3):
+        res = o.decode(g["f%d_llr" % f], 16, 32, 0.3, 10, want_state=True, want_sweeps=True)
+        apps, decs, synds = g["f%d_app" % f], g["f%d_dec" % f], g["f%d_synd" % f]
+        assert len(synds) == len(res["sweep_synd"])
+        assert (res["sweep_synd"] == synds).all() and (res["sweep_decide"] == decs).all()
+        assert res["app"].tobytes() == apps[-1].tobytes()
+        for s in range(len(synds)):
+            assert res["sweep_crc"][s] == orc.crc32(apps[s])
+    # constants recorded from the reference in SURVEY.md 8(c), K1 detail
+    assert list(g["f0_cw"]) == [41, 8, 29, 49, 19, 2, 47, 0, 62, 35, 55, 21, 45, 49, 29, 49]
+    assert list(g["f1_dec"][-1]) == [1, 6, 62, 5, 22, 1, 6, 44, 31, 0, 39, 54, 1, 40, 7, 32]
+    assert np.allclose(g["f0_app"][-1][0][:4], [26.994837, 20.748087, 22.907717, 21.581903], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,mat,nm,nop", [("gf16", "Ahmed_64800_R34_GF16", 8, 16), ("gf256", "Ahmed_64800_R12_GF256", 20, 40)])
+def test_trajectory_big_codes(orc, tag, mat, nm, nop):
+    g = gold("traj_big.npz")
+    o = orc.Oracle(os.path.join(MAT, mat))
+    rng = orc.Rng(0)
+    sigma = o.sigma(float(g[tag + "_ebn"]))
+    cw, noisy = o.draw_frame(rng, sigma)
+    assert (cw == g[tag + "_cw"]).all()
+    res = o.decode(o.llr(noisy, sigma), nm, nop, 0.3, 30, want_sweeps=True)
+    assert res["iters"] == int(g[tag + "_iters"])
+    assert (res["sweep_crc"] == g[tag + "_crc"]).all() and (res["sweep_decide"] == g[tag + "_dec"]).all()
+
+
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5"])
+def test_kat_traces(orc, kat, name):
+    """End-to-end FER/BER/avr_it traces printed by the reference executable."""
+    k = kat[name]
+    matrix = {"KN/N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    if name in ("K1", "K2"):
+        matrix = "KN_N96_K48_GF64.txt"
+    o = orc.Oracle(os.path.join(MAT, matrix))
+    rec = o.sim(orc.Rng(0), k["EbN"], k["nm"], k["NbOper"], k["offset"], k["NbIterMax"], k["frames"])
+    tr = orc.trace_from_records(rec, o.K, o.logq)
+    assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
