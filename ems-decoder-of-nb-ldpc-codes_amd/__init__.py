@@ -76,6 +76,8 @@ def lib():
         L.ems_get_results.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ems_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ems_count_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ems_set_codewords.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ems_count_errors_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_app.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_ctov.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -204,6 +206,15 @@ class Decoder:
         B = cw.shape[0]
         out = np.zeros(B, np.int32)
         _check(lib().ems_count_errors(self.h, _ptr(cw), B, _ptr(out)))
+        return out
+
+    def set_codewords(self, codewords):
+        cw = np.ascontiguousarray(codewords, np.int32)
+        _check(lib().ems_set_codewords(self.h, _ptr(cw), cw.shape[0]))
+
+    def count_errors_resident(self, B):
+        out = np.zeros(B, np.int32)
+        _check(lib().ems_count_errors_resident(self.h, B, _ptr(out)))
         return out
 
     # ---- introspection ----

@@ -486,6 +486,29 @@ int ems_count_errors(ems_handle *h, const int *cw_host, int B, int *nb_errors)
     return EMS_OK;
 }
 
+
+int ems_set_codewords(ems_handle *h, const int *cw_host, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!cw_host) return fail(EMS_EINVAL, "null argument");
+    HIP_TRY(hipMemcpyAsync(h->d_cw.p, cw_host, sizeof(int) * (size_t)B * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+int ems_count_errors_resident(ems_handle *h, int B, int *nb_errors)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    HIP_TRY(ems_launch_count_errors(h->d_decide.p, h->d_cw.p, B, h->N, h->K, h->d_i2b.p, h->d_nberr.p, h->stream));
+    if (nb_errors) {
+        HIP_TRY(hipMemcpyAsync(nb_errors, h->d_nberr.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return EMS_OK;
+}
+
 int ems_get_app(ems_handle *h, int frame, float *app)
 {
     int r = check_batch(h, frame + 1);

@@ -89,6 +89,11 @@ int ems_decode_batch(ems_handle *h, const float *noisy_host, float sigma, int B,
 /* NB_LDPC.c:479-485 bit errors over the first K symbols against the transmitted codewords [B][N]. */
 int ems_count_errors(ems_handle *h, const int *codewords_host, int B, int *nb_errors /*[B]*/);
 
+/* Device-resident variant for benchmark drivers: upload the codewords once, then count per step;
+ * nb_errors may be NULL (result stays on the device). */
+int ems_set_codewords(ems_handle *h, const int *codewords_host, int B);
+int ems_count_errors_resident(ems_handle *h, int B, int *nb_errors /*[B] or NULL*/);
+
 /* ---- introspection for parity tests ---- */
 int ems_get_app(ems_handle *h, int frame, float *app /*[N][GF]*/);   /* decoder_t.APP after decode      */
 int ems_get_ctov(ems_handle *h, int frame, float *ctov /*[E][GF]*/); /* decoder_t.CtoV, expanded dense */
