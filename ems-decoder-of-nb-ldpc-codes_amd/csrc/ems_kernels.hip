@@ -277,12 +277,166 @@ __device__ __forceinline__ void select_rounds(const float (&mvc)[Geo<Q, LPE>::EP
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast top-nm selection (same result as select_rounds, ~8x fewer instructions).
+//   A. find a threshold T with nm <= #{v <= T} <= CAP by counting (secant/bisection between the row
+//      minimum and the largest lane-local minimum; every decision is taken on an exact count, the
+//      float arithmetic only steers the search);
+//   B. compact the survivors {v <= T} of each row into LDS as (value bits, symbol) pairs;
+//   C. rank them exactly by the 64-bit key (order-preserving image of the float, symbol) -- ties
+//      -> lowest symbol, -0 == +0 -- and let the survivors of rank < nm write the normalised
+//      (NB_LDPC.c:372-373), rotated (bubble_decoder.c:133-152) message entry.
+// Returns false (wave-uniform) when some row found no such T (huge tie groups, e.g. a noiseless
+// channel): the caller then runs the literal select_rounds path.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_CAP = 32;
+
+__device__ __forceinline__ unsigned mono_key(float v)
+{
+    const unsigned b = (unsigned)__float_as_int(v + 0.0f);     // -0 -> +0
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
+template <int LPE, typename F> __device__ __forceinline__ float row_reduce_f(float x, F better)
+{
+    float o;
+    o = dpp_f<DPP_XOR1>(x); x = better(o, x) ? o : x;
+    o = dpp_f<DPP_XOR2>(x); x = better(o, x) ? o : x;
+    o = dpp_f<DPP_HMIRROR>(x); x = better(o, x) ? o : x;
+    if (LPE == 16) { o = dpp_f<DPP_MIRROR>(x); x = better(o, x) ? o : x; }
+    return x;
+}
+template <int LPE> __device__ __forceinline__ int row_sum_i(int x)
+{
+    x += dpp_i<DPP_XOR1>(x);
+    x += dpp_i<DPP_XOR2>(x);
+    x += dpp_i<DPP_HMIRROR>(x);
+    if (LPE == 16) x += dpp_i<DPP_MIRROR>(x);
+    return x;
+}
+// exclusive prefix sum over the LPE lanes of a row (row_shr shifts; contributions from outside the row masked)
+template <int LPE> __device__ __forceinline__ int row_excl_scan_i(int x, int rl)
+{
+    int inc = x, t;
+    t = dpp_i<0x111>(inc); inc += (rl >= 1) ? t : 0;
+    t = dpp_i<0x112>(inc); inc += (rl >= 2) ? t : 0;
+    t = dpp_i<0x114>(inc); inc += (rl >= 4) ? t : 0;
+    if (LPE == 16) { t = dpp_i<0x118>(inc); inc += (rl >= 8) ? t : 0; }
+    return inc - x;
+}
+
+template <int Q, int LPE>
+__device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
+                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact)
+{
+    using G = Geo<Q, LPE>;
+    constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
+    // ---- A ----
+    float lmin = mvc[0];
+#pragma unroll
+    for (int e = 1; e < G::EPL; ++e) lmin = (mvc[e] < lmin) ? mvc[e] : lmin;
+    const float rmin = row_reduce_f<LPE>(lmin, [](float a, float b) { return a < b; });
+    float T = __builtin_inff();
+    int cnt = Q;
+    bool done = true;
+    if (Q > SEL_CAP) {
+        const float rmaxl = row_reduce_f<LPE>(lmin, [](float a, float b) { return a > b; });
+        float lo = rmin, hi = rmaxl;
+        int clo = 1, chi = 0;
+        bool hiv = false;
+        T = rmaxl;
+        done = false;
+        for (int it = 0; it < 12; ++it) {
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < G::EPL; ++e) c += (mvc[e] <= T) ? 1 : 0;
+            c = row_sum_i<LPE>(c);
+            if (!done) {
+                cnt = c;
+                if (c >= nm && c <= SEL_CAP) {
+                    done = true;
+                } else {
+                    if (c < nm) { lo = T; clo = c; } else { hi = T; chi = c; hiv = true; }
+                    float nt;
+                    if (!hiv) {
+                        nt = T + (T - rmin) + 1.0f;                        // gallop upward
+                    } else {
+                        float fr = (float)((nm + SEL_CAP) / 2 - clo) / (float)(chi - clo);
+                        fr = fr < 0.125f ? 0.125f : (fr > 0.875f ? 0.875f : fr);
+                        nt = lo + (hi - lo) * fr;
+                        if (!(nt > lo && nt < hi)) nt = lo + (hi - lo) * 0.5f;
+                        if (!(nt > lo && nt < hi)) nt = hi;                // no float in between: give up below
+                    }
+                    T = nt;
+                }
+            }
+            if (__ballot(!done) == 0ull) break;
+        }
+    }
+    if (__ballot(!done) != 0ull) return false;
+
+    // ---- B ----
+    int lc = 0;
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) lc += (mvc[e] <= T) ? 1 : 0;
+    int off = row_excl_scan_i<LPE>(lc, rl);
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) {
+        const bool sv = mvc[e] <= T;
+        surv[sv ? off : SEL_CAP + rl] = EmsEntry{mvc[e], (unsigned)G::sym_of(e, rl)};
+        off += sv ? 1 : 0;
+    }
+    wave_lds_sync();
+
+    // ---- C ----
+    EmsEntry my[SPL];
+    unsigned long long key[SPL];
+    int rank[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int idx = rl + k * LPE;
+        const bool valid = idx < cnt;
+        my[k] = surv[idx];
+        key[k] = valid ? (((unsigned long long)mono_key(my[k].v) << 32) | my[k].s) : ~0ull;
+        rank[k] = valid ? 0 : 0x7FFF;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int idx = rl + k * LPE;
+        *reinterpret_cast<unsigned long long *>(&surv[idx]) = key[k];   // mono keys; slots >= cnt get the max key
+    }
+    wave_lds_sync();
+    int cmax = 0;
+#pragma unroll
+    for (int r = 0; r < G::NROWS; ++r) cmax = max(cmax, __builtin_amdgcn_readlane(cnt, r * LPE));
+    for (int j = 0; j < cmax; ++j) {
+        const unsigned long long kj = *reinterpret_cast<const unsigned long long *>(&surv[j]);
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) rank[k] += (kj < key[k]) ? 1 : 0;
+    }
+    const float v0 = rmin < EMS_SENTINEL ? rmin : EMS_SENTINEL;         // the first selected value
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        if (rowact && rank[k] < nm) {
+            const bool ok = my[k].v < EMS_SENTINEL;                     // NB_LDPC.c:358-366
+            const float v = ok ? my[k].v : EMS_SENTINEL;
+            const int g = ok ? (int)my[k].s : 0;
+            const int gi = gf_mul_log(g, lh, Q - 1);
+            inl[rank[k]] = EmsEntry{rank[k] == 0 ? 0.0f : v - v0, (unsigned)t_i2b[gi]};
+        }
+    }
+    (void)lane;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One check-node visit by one wave: NB_LDPC.c:329-450 around bubble_decoder.c:72-305.
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool first_sweep, const uint8_t *t_i2b,
-                                           const uint8_t *t_b2i, float *dense, EmsEntry *lists, int *lens, int lane)
+                                           const uint8_t *t_b2i, float *dense, EmsEntry *surv, EmsEntry *lists, int *lens, int lane)
 {
     using G = Geo<Q, LPE>;
     const int rl = lane & (LPE - 1);
@@ -316,10 +470,10 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
 
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
     EmsEntry *inl = lists + t * nm;
-    select_rounds<Q, LPE>(mvc, inl, rl, nm);
-    wave_lds_sync();
-    // ---- normalise (:372-373) and rotate by the edge coefficient (bubble_decoder.c:133-152) ----
-    {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact)) {
+        // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
+        select_rounds<Q, LPE>(mvc, inl, rl, nm);
+        wave_lds_sync();
         constexpr int NT = (EMS_MAX_NM + LPE - 1) / LPE;
         const float v0 = inl[0].v;
         EmsEntry tmp[NT];
@@ -407,8 +561,10 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
 
     uint8_t *wbase = smem + wg_header_bytes<Q>() + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
-    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
-    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + ((P.n_lists * P.nm * 8 + 15) & ~15));
+    constexpr int SURV_BYTES = G::NROWS * (SEL_CAP + LPE) * 8;       // survivor scratch of the selection
+    EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
+    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((P.n_lists * P.nm * 8 + 15) & ~15));
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
@@ -423,7 +579,7 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
         for (int lv = 0; lv < P.n_levels; ++lv) {              // NB_LDPC.c:320, level by level
             const int b = P.lvl_ptr[lv], e = P.lvl_ptr[lv + 1];
             for (int i = b + wave; i < e; i += nwaves)
-                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, lists, lens, lane);
+                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, lane);
             __syncthreads();
         }
         // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero
@@ -631,7 +787,7 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {
     const int lpe = ems_lpe_for(dc);
     if (!lpe) return 0;
-    const size_t dense = (size_t)(64 / lpe) * q * 4;
+    const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * (32 + lpe) * 8; // staging rows + survivor scratch
     const size_t lists = ((size_t)n_lists * nm * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
     return dense + lists + lens;
