@@ -15,7 +15,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libems_hip.so")
+LIB_PATH = os.environ.get("EMS_LIB") or os.path.join(PKG_DIR, "libems_hip.so")  # EMS_LIB: developer override (ablation builds)
 SIM_PATH = os.path.join(PKG_DIR, "ems_sim")
 
 EMS_OK, EMS_EINVAL, EMS_ENODEV, EMS_EHIP, EMS_EIO, EMS_ENOMEM, EMS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6

@@ -187,6 +187,7 @@ struct ems_handle {
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
+    DevBuf<unsigned long long> d_stamps;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_llr_ev = false, have_dec_ev = false;
@@ -220,6 +221,7 @@ int refresh_plan(ems_handle *h)
     while (waves > 1 && ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) --waves;
     if (ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
     P.waves_per_wg = waves;
+    P.stamps = h->d_stamps.p;
     return EMS_OK;
 }
 
@@ -334,7 +336,7 @@ void ems_destroy(ems_handle *h)
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
-    h->d_scratch.release();
+    h->d_scratch.release(); h->d_stamps.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -384,7 +386,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
-        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)))
+        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))
         return bail(r);
     if ((r = refresh_plan(h))) return bail(r);
     *out = h;
@@ -526,7 +528,7 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov)
     if (!ctov || frame < 0) return fail(EMS_EINVAL, "bad argument");
     const size_t n = (size_t)h->E * h->q;
     if (h->d_scratch.n < n) {
-        h->d_scratch.release();
+        h->d_scratch.release(); h->d_stamps.release();
         if ((r = h->d_scratch.alloc(n))) return r;
     }
     const int rb = ems_rec_bytes(h->nm_alloc);
@@ -576,6 +578,18 @@ int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr, int *order)
     return EMS_OK;
 }
 
+
+/* developer diagnostics (EMS_STAMPS builds): zero / read the 16 per-phase cycle accumulators */
+int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset)
+{
+    if (!h) return fail(EMS_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out16) HIP_TRY(hipMemcpy(out16, h->d_stamps.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->d_stamps.p, 0, 16 * sizeof(unsigned long long)));
+    return EMS_OK;
+}
+
 float ems_last_llr_ms(const ems_handle *h)
 {
     float ms = -1.f;
@@ -622,7 +636,7 @@ int ems_elementary_step(int GF, int nm, int nbOper, const float *in1, const floa
     int *di1 = t.up(idx1, nm), *di2 = t.up(idx2, nm), *dio = t.up<int>(nullptr, nm);
     uint8_t *da = t.up(i2b, 256), *db = t.up(b2i, 256);
     if (!d1 || !d2 || !dout || !di1 || !di2 || !dio || !da || !db) return fail(EMS_ENOMEM, "device allocation failed");
-    HIP_TRY(ems_launch_es_unit(d1, d2, di1, di2, dout, dio, nm, nbOper, da, db, nullptr));
+    HIP_TRY(ems_launch_es_unit(d1, d2, di1, di2, dout, dio, nm, nbOper, GF, da, db, nullptr));
     HIP_TRY(hipMemcpy(out, dout, sizeof(float) * nm, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(idxout, dio, sizeof(int) * nm, hipMemcpyDeviceToHost));
     return EMS_OK;

@@ -18,7 +18,7 @@ hipError_t ems_launch_count_errors(const uint8_t *decide_dev, const int *cw_dev,
 hipError_t ems_launch_expand_ctov(const uint8_t *rec_dev, int rec_bytes, int nm, int q, int E, float *out_dev,
                                   hipStream_t st);
 hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
-                              int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx,
+                              int *idxout, int nm, int nbOper, int q, const uint8_t *idx2bin, const uint8_t *bin2idx,
                               hipStream_t st);
 hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov,
                               hipStream_t st);

@@ -26,6 +26,14 @@
 
 namespace {
 
+// Diagnostic build only (-DEMS_STAMPS): per-phase shader-cycle totals of the check-node visits,
+// accumulated per wave and added to P.stamps at kernel end.  Never compiled into the product.
+#ifdef EMS_STAMPS
+#define STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // cross-lane helpers (GFX9 DPP controls)
 // ------------------------------------------------------------------------------------------------
@@ -178,19 +186,205 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
     if (has && p == 0) lens[o_id] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ElementaryStep, fast form.  The bubble loop of bubble_decoder.c:472-562 is a stable 8-way merge whose
+// pick sequence does not depend on the output bookkeeping, so it is split in two:
+//   1. the serial loop only merges: per step one 8-lane min, the lowest competitor among the ties,
+//      the winner records (competitor, position) as one byte and advances -- ~25 instructions;
+//   2. a parallel post-pass over the T recorded picks recomputes value + symbol of every pick, finds
+//      the first stop (invalid source index -> before the pick, bubble_decoder.c:478; last row/column
+//      -> after it, :506), removes symbols already emitted (first occurrence wins, :490; one
+//      ds_max per pick on a q-entry LDS table) and compacts the survivors in order, cutting at nm (:502).
+// The loop first runs nm+3 steps (the reference needs 20.3 on average at nm = 20); only if some group
+// has neither nm outputs nor a stop by then does it continue to nbOper and repeat the post-pass.
+// Values inside the check node are non-negative floats (normalised inputs and their sums), so the
+// IEEE order equals the unsigned order of the bit patterns; the loop compares bit patterns.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned SENT_BITS = 0x47C35000u; // bit pattern of 1e5f
+constexpr int ES_MAX_STEPS = 64;
+
+__device__ __forceinline__ unsigned red8_minu(unsigned x)
+{
+    x = min(x, (unsigned)dpp_i<DPP_XOR1>((int)x));
+    x = min(x, (unsigned)dpp_i<DPP_XOR2>((int)x));
+    x = min(x, (unsigned)dpp_i<DPP_HMIRROR>((int)x));
+    return x;
+}
+
+template <int NJ>
+__device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
+                                        const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
+                                        int nbOper, int &S_out)
+{
+    wave_lds_sync();
+    if (has)
+        for (int w = p * 4; w < q; w += 32) *reinterpret_cast<uint4 *>(tbl + w) = uint4{0u, 0u, 0u, 0u};
+    float val[NJ];
+    unsigned sym[NJ];
+    int lim = 1 << 20;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        const bool ok = has && i < T;
+        const unsigned pk = picks[ok ? i : 0];
+        const int w = pk & 7, k = pk >> 3;
+        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
+        const EmsEntry e1 = in1[r], e2 = in2[c];
+        val[j] = e1.v + e2.v;
+        const unsigned sy = sym_comb(e1.s, e2.s);
+        sym[j] = sy & 0xFFu;
+        const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
+        lim = min(lim, li);
+    }
+    lim = red8_mini(lim);
+    const bool stopped = lim <= T;
+    lim = min(lim, T);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        if (has && i < lim) atomicMax(&tbl[sym[j]], (unsigned)(ES_MAX_STEPS - i));
+    }
+    wave_lds_sync();
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const int sidx = base + __popc(m8 & ((1u << p) - 1u));
+        if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
+        base += __popc(m8);
+    }
+    S_out = min(base, nm);
+    return (base >= nm) || stopped || (T >= nbOper);
+}
+
+
+// Register-light form of es_post for the rare continuation (T up to 64 picks): same algorithm, the
+// per-pick value/symbol are recomputed in each of the three passes instead of being kept in registers.
+__device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
+                                           const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
+                                           int nbOper, int &S_out)
+{
+    const int NJ = (T + 7) >> 3;
+    auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &k) {
+        const unsigned pk = picks[ok ? i : 0];
+        const int w = pk & 7;
+        k = pk >> 3;
+        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
+        const EmsEntry e1 = in1[r], e2 = in2[c];
+        v = e1.v + e2.v;
+        sy = sym_comb(e1.s, e2.s);
+    };
+    wave_lds_sync();
+    if (has)
+        for (int w = p * 4; w < q; w += 32) *reinterpret_cast<uint4 *>(tbl + w) = uint4{0u, 0u, 0u, 0u};
+    int lim = 1 << 20;
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        const bool ok = has && i < T;
+        float v; unsigned sy; int k;
+        gather(i, ok, v, sy, k);
+        const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
+        lim = min(lim, li);
+    }
+    lim = red8_mini(lim);
+    const bool stopped = lim <= T;
+    lim = min(lim, T);
+    wave_lds_sync();
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        float v; unsigned sy; int k;
+        gather(i, has && i < T, v, sy, k);
+        if (has && i < lim) atomicMax(&tbl[sy & 0xFFu], (unsigned)(ES_MAX_STEPS - i));
+    }
+    wave_lds_sync();
+    int base = 0;
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        float v; unsigned sy; int k;
+        gather(i, has && i < T, v, sy, k);
+        const bool u = has && i < lim && tbl[sy & 0xFFu] == (unsigned)(ES_MAX_STEPS - i);
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const int sidx = base + __popc(m8 & ((1u << p) - 1u));
+        if (u && sidx < nm) out[sidx] = EmsEntry{v, sy & 0xFFu};
+        base += __popc(m8);
+    }
+    S_out = min(base, nm);
+    return (base >= nm) || stopped || (T >= nbOper);
+}
+
+__device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
+                                              int lane, int a_id, int b_id, int o_id, int nm, int nbOper)
+{
+    const int p = lane & 7;
+    const int gbase = lane & ~7;
+    const int gsel = (lane >> 3) & 3;
+    const bool has = o_id >= 0;
+    const EmsEntry *in1 = lists + (has ? a_id : 0) * nm;
+    const EmsEntry *in2 = lists + (has ? b_id : 0) * nm;
+    EmsEntry *out = lists + (has ? o_id : 0) * nm;
+    unsigned *tbl = tbl_base + gsel * q;
+    uint8_t *picks = picks_base + gsel * ES_MAX_STEPS;
+    uint8_t *dummy = picks_base + 4 * ES_MAX_STEPS + lane;
+
+    if (has)
+        for (int k = p; k < nm; k += 8) out[k] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID}; // :370-374
+
+    const bool rowc = p < 4;
+    const EmsEntry *mv = rowc ? in2 : in1;
+    int pos = rowc ? 0 : 4;
+    const float fxv = rowc ? in1[p].v : in2[p - 4].v;
+    unsigned hv = (unsigned)__float_as_int(fxv + mv[pos].v);
+    float nxv = mv[min(pos + 1, nm - 1)].v;
+
+    auto run = [&](int from, int to) {
+        for (int ss = from; ss < to; ++ss) {
+            const unsigned m = red8_minu(hv);                       // minimum(): smallest head ...
+            const unsigned long long eqb = __ballot(hv == m);
+            int wp = __ffs((unsigned)(eqb >> gbase)) - 1;           // ... first competitor holding it
+            wp = (m < SENT_BITS) ? wp : 0;                          // nothing below 1e5 -> competitor 0
+            const bool iw = has && (p == wp);
+            *(iw ? picks + ss : dummy) = (uint8_t)(p | (pos << 3));
+            const int posn = pos + (iw ? 1 : 0);
+            unsigned nh = (unsigned)__float_as_int(fxv + nxv);
+            nh = posn < nm ? nh : 0xFFFFFFFFu;                      // walked off the list: never wins again
+            hv = iw ? nh : hv;
+            pos = posn;
+            nxv = mv[min(pos + 1, nm - 1)].v;
+        }
+    };
+
+    int S = 0;
+    bool done;
+    const int T1 = min(nbOper, nm + 3);
+    run(0, T1);
+    if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    if (__ballot(has && !done) != 0ull) {
+        run(T1, nbOper);
+        es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
+    }
+    if (has && p == 0) lens[o_id] = S;
+}
+
 // Forward/backward recursion + merges of CheckPassLogEMS (bubble_decoder.c:166-227) as a static task
 // table: step t runs P[t] = ES(P[t-1], in[t]), S[dc-1-t] = ES(S[dc-t], in[dc-1-t]) and every merge
 // ES(P[k], S[k+2]) whose operands became available after step t-1, side by side on 8-lane groups.
-__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, int lane)
+__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane)
 {
     const int grp = lane >> 3;
+    const bool fast = P.nbOper <= ES_MAX_STEPS;
     for (int t = 0; t < P.nsteps; ++t) {
         int a = -1, b = -1, o = -1;
         if (grp < 4) {
             const int8_t *sc = P.sched + (t * 4 + grp) * 3;
             a = sc[0]; b = sc[1]; o = sc[2];
         }
-        es_stage(lists, lens, lane, a, b, o, P.nm, P.nbOper);
+        if (fast) es_stage_fast(lists, lens, tbl, picks, P.q, lane, a, b, o, P.nm, P.nbOper);
+        else es_stage(lists, lens, lane, a, b, o, P.nm, P.nbOper);
         wave_lds_sync();
     }
 }
@@ -436,7 +630,11 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool first_sweep, const uint8_t *t_i2b,
-                                           const uint8_t *t_b2i, float *dense, EmsEntry *surv, EmsEntry *lists, int *lens, int lane)
+                                           const uint8_t *t_b2i, float *dense, EmsEntry *surv, EmsEntry *lists, int *lens, uint8_t *picks, int lane
+#ifdef EMS_STAMPS
+                                           , unsigned long long (&st_acc)[8], unsigned long long &st_last
+#endif
+                                           )
 {
     using G = Geo<Q, LPE>;
     const int rl = lane & (LPE - 1);
@@ -468,8 +666,13 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
         for (int e = 0; e < G::EPL; ++e) mvc[e] = mvc[e] - c[e];
     }
 
+    STAMP(0);
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
     EmsEntry *inl = lists + t * nm;
+#ifdef EMS_ABLATE_SEL
+    for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
+    if (false)
+#endif
     if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
@@ -493,9 +696,16 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
     }
     wave_lds_sync();
 
+    STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
-    cn_core(P, lists, lens, lane);
+#ifndef EMS_ABLATE_ES
+    cn_core(P, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane);
+#else
+    if (lane < 16) lens[lane < P.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
+    wave_lds_sync();
+#endif
 
+    STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
     const int oid = P.out_list[t];
@@ -536,6 +746,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
     row_argmin<LPE>(lv, lg);
     if (rowact && rl == 0) P.decide[(size_t)f * P.N + vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
     wave_lds_sync();
+    STAMP(3);
 }
 
 // LDS carve of a workgroup: [idx2bin Q][bin2idx Q][first-nonzero-syndrome word, padded to 16] then one
@@ -565,6 +776,7 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
     int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((P.n_lists * P.nm * 8 + 15) & ~15));
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((P.n_lists * 4 + 15) & ~15);   // 4 x 64 pick bytes + 64 dummies
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
@@ -573,14 +785,24 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
     if (tid == 0) *first_bad = 0xFFFFFFFFu;
     __syncthreads();
 
+#ifdef EMS_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
     int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
     unsigned synd = 0;
     for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
         for (int lv = 0; lv < P.n_levels; ++lv) {              // NB_LDPC.c:320, level by level
             const int b = P.lvl_ptr[lv], e = P.lvl_ptr[lv + 1];
             for (int i = b + wave; i < e; i += nwaves)
-                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, lane);
+                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
+#ifdef EMS_STAMPS
+                                   , st_acc, st_last
+#endif
+                );
+            STAMP(6);
             __syncthreads();
+            STAMP(4);
         }
         // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero
         //      sum; 0 iff codeword.  One thread per check node.
@@ -598,11 +820,16 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
         __syncthreads();
         if (tid == 0) *first_bad = 0xFFFFFFFFu;
         synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        STAMP(5);
         if (synd == 0 && P.early_exit) {                       // NB_LDPC.c:470-471
             it = sweep + 1;
             break;
         }
     }
+#ifdef EMS_STAMPS
+    if (lane == 0 && P.stamps)
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[(wave < 9 ? 0 : 8) + i], st_acc[i]);
+#endif
     if (tid == 0) {
         P.iters[f] = it;
         P.synd[f] = (int)synd;
@@ -694,10 +921,12 @@ __global__ void k_expand_ctov(const uint8_t *__restrict__ rec_base, int rec_byte
 // Decision / Syndrom symbols: same device functions as the decode kernel.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
-                          int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx)
+                          int *idxout, int nm, int nbOper, int q, const uint8_t *idx2bin, const uint8_t *bin2idx)
 {
     __shared__ EmsEntry lists[3 * EMS_MAX_NM];
     __shared__ int lens[4];
+    __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
+    __shared__ uint8_t picks[5 * 64];
     const int lane = threadIdx.x;
     for (int k = lane; k < nm; k += 64) {
         lists[k] = EmsEntry{in1[k], idx1[k] < 0 ? EMS_S_INVALID : (unsigned)idx2bin[idx1[k]]};
@@ -705,7 +934,8 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     }
     wave_lds_sync();
     const bool g0 = lane < 8;
-    es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+    if (nbOper <= ES_MAX_STEPS) es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+    else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
         const EmsEntry e = lists[2 * nm + k];
@@ -720,6 +950,8 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(smem);
     int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * P.nm * 8 + 15) & ~15));
+    __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
+    __shared__ uint8_t picks[5 * 64];
     const int lane = threadIdx.x;
     const int nm = P.nm, dc = P.dc;
     for (int i = lane; i < dc * nm; i += 64) {                 // rotation, bubble_decoder.c:133-152
@@ -728,7 +960,7 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
         lists[i] = EmsEntry{vtoc_llr[i], g < 0 ? EMS_S_INVALID : (unsigned)P.idx2bin[gf_mul_log(g, coef[t] - 1, Q - 1)]};
     }
     wave_lds_sync();
-    cn_core(P, lists, lens, lane);
+    cn_core(P, lists, lens, tbl, picks, lane);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
         const EmsEntry *ol = lists + oid * nm;
@@ -790,7 +1022,7 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
     const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * (32 + lpe) * 8; // staging rows + survivor scratch
     const size_t lists = ((size_t)n_lists * nm * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens;
+    return dense + lists + lens + 5 * 64; // + pick bytes of the elementary steps
 }
 
 size_t ems_wg_lds_bytes(int q, size_t wave_bytes, int waves) { return (size_t)2 * q + 16 + wave_bytes * waves; }
@@ -845,10 +1077,10 @@ hipError_t ems_launch_expand_ctov(const uint8_t *rec_dev, int rec_bytes, int nm,
 }
 
 hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
-                              int *idxout, int nm, int nbOper, const uint8_t *idx2bin, const uint8_t *bin2idx,
+                              int *idxout, int nm, int nbOper, int q, const uint8_t *idx2bin, const uint8_t *bin2idx,
                               hipStream_t st)
 {
-    hipLaunchKernelGGL(k_es_unit, dim3(1), dim3(64), 0, st, in1, in2, idx1, idx2, out, idxout, nm, nbOper, idx2bin,
+    hipLaunchKernelGGL(k_es_unit, dim3(1), dim3(64), 0, st, in1, in2, idx1, idx2, out, idxout, nm, nbOper, q, idx2bin,
                        bin2idx);
     return hipGetLastError();
 }

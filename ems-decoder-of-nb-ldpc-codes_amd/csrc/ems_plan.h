@@ -55,4 +55,5 @@ struct EmsPlan {
     int rec_bytes;
     int wave_lds_bytes;     // LDS per wave
     int waves_per_wg;
+    unsigned long long *stamps; // diagnostic builds only (EMS_STAMPS), else null
 };

@@ -128,6 +128,9 @@ float ems_last_decode_ms(const ems_handle *h);
 void *ems_noisy_dev_ptr(ems_handle *h);
 void *ems_stream(ems_handle *h);
 int ems_synchronize(ems_handle *h);
+/* Developer diagnostics: per-phase cycle accumulators of builds compiled with -DEMS_STAMPS (all zero
+ * in the product build). */
+int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset);
 const char *ems_last_error(void);
 const char *ems_version(void);
 

@@ -1,0 +1,33 @@
+"""Developer probe: per-phase cycle shares of the decode kernel (needs build/libems_stamps.so, -DEMS_STAMPS)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("EMS_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libems_stamps.so"))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+W = {"gf256": ("Ahmed_64800_R12_GF256", 20, 40, 30, 1.0, 256), "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 30, 0.0, 256),
+     "n96": ("N96_K48_GF64", 16, 32, 30, -3.0, 8192)}
+names = ["load+Mvc", "select", "ES stages", "expand+store+decide", "level barrier wait", "syndrome", "wave idle (no CN)", "-"]
+for w in (sys.argv[1:] or ["gf256"]):
+    B = None
+    if ":" in w: w, B = w.split(":"); B = int(B)
+    name, nm, nop, itmax, ebn, B0 = W[w]; B = B or B0
+    code = pkg.Code(os.path.join(ge.MATRICES, name))
+    rs = np.random.RandomState(1)
+    sigma = float(np.sqrt(1.0 / (2 * float(code.rate) * 10 ** (ebn / 10))))
+    noisy = (1.0 + sigma * rs.randn(B, code.N, code.logGF)).astype(np.float32)
+    dec = pkg.Decoder(code, nm, nop, 0.3, itmax, max_batch=B, early_exit=False)
+    L = pkg.lib(); L.ems_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    dec.llr_init(noisy, sigma); dec.decode(B); dec.synchronize()
+    L.ems_debug_stamps(dec.h, None, 1)
+    dec.llr_init(noisy, sigma); dec.decode(B); dec.synchronize()
+    st = np.zeros(16, np.uint64); L.ems_debug_stamps(dec.h, st.ctypes.data_as(C.c_void_p), 0)
+    ms = dec.last_decode_ms
+    print("%s B=%d decode %.2f ms (stamped build)" % (w, B, ms))
+    for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
+        tot = float(st[grp:grp + 8].sum()) or 1.0
+        print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(7)))
+    w0 = st[0:8].astype(np.float64); nw = min(9, dec and 9) * B
+    per_wave_cycles = w0.sum() / nw
+    print("  cycles per wave (waves 0-8 avg): %.3e ; => clock ~ %.2f GHz if the kernel took %.1f ms" % (per_wave_cycles, per_wave_cycles / (ms * 1e-3) / 1e9, ms))
+    dec.close()
