@@ -180,10 +180,10 @@ struct ems_handle {
     int device = 0, max_batch = 0, nm_alloc = 0;
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
-    std::vector<int> lvl_ptr, lvl_cn, cn_vn;
+    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred;
     std::vector<uint8_t> cn_lh, i2b, b2i;
     CnSchedule cs;
-    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr;
+    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
@@ -208,7 +208,8 @@ int refresh_plan(ems_handle *h)
     P.offset = p.offset;
     P.n_levels = (int)h->lvl_ptr.size() - 1;
     P.lvl_ptr = h->d_lvl_ptr.p; P.lvl_cn = h->d_lvl_cn.p; P.cn_vn = h->d_cn_vn.p; P.cn_lh = h->d_cn_lh.p;
-    P.nsteps = h->cs.nsteps; P.sched = h->d_sched.p; P.n_lists = h->cs.n_lists;
+    P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
+    P.t_cn = h->d_lvl_cn.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
@@ -218,8 +219,8 @@ int refresh_plan(ems_handle *h)
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
     int waves = std::min(16, widest);
     const size_t lds_cap = 160 * 1024;
-    while (waves > 1 && ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) --waves;
-    if (ems_wg_lds_bytes(h->q, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
+    while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
+    if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
     P.waves_per_wg = waves;
     P.stamps = h->d_stamps.p;
     return EMS_OK;
@@ -336,7 +337,7 @@ void ems_destroy(ems_handle *h)
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
-    h->d_scratch.release(); h->d_stamps.release();
+    h->d_scratch.release(); h->d_stamps.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -376,6 +377,29 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     h->cn_lh.resize(E);
     for (long e = 0; e < E; ++e) h->cn_lh[e] = (uint8_t)(c->coef[e] - 1);
     if ((r = level_schedule(c, h->lvl_ptr, h->lvl_cn))) return bail(r);
+    // Task descriptors in level order; per edge the task index of the previous visitor (reference order)
+    // of its variable node within the same sweep.
+    {
+        std::vector<int> task_of(h->M), last_cn(h->N, -1);
+        for (int i = 0; i < h->M; ++i) task_of[h->lvl_cn[i]] = i;
+        std::vector<int> pred_cn((size_t)E, -1);
+        for (int m = 0; m < h->M; ++m)
+            for (int i = 0; i < h->dc; ++i) {
+                const int v = c->col[m * h->dc + i];
+                pred_cn[(size_t)m * h->dc + i] = last_cn[v];
+                last_cn[v] = m;
+            }
+        h->t_vn.resize(E); h->t_lh.resize(E); h->t_pred.resize(E);
+        for (int i = 0; i < h->M; ++i) {
+            const int m = h->lvl_cn[i];
+            for (int k = 0; k < h->dc; ++k) {
+                const size_t e = (size_t)m * h->dc + k;
+                h->t_vn[(size_t)i * h->dc + k] = c->col[e];
+                h->t_lh[(size_t)i * h->dc + k] = c->coef[e] - 1;
+                h->t_pred[(size_t)i * h->dc + k] = pred_cn[e] < 0 ? -1 : task_of[pred_cn[e]];
+            }
+        }
+    }
 
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
@@ -383,7 +407,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     const size_t B = (size_t)max_batch;
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
-        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))
@@ -528,7 +552,7 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov)
     if (!ctov || frame < 0) return fail(EMS_EINVAL, "bad argument");
     const size_t n = (size_t)h->E * h->q;
     if (h->d_scratch.n < n) {
-        h->d_scratch.release(); h->d_stamps.release();
+        h->d_scratch.release();
         if ((r = h->d_scratch.alloc(n))) return r;
     }
     const int rb = ems_rec_bytes(h->nm_alloc);
@@ -579,6 +603,17 @@ int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr, int *order)
 }
 
 
+/* developer diagnostics: print the device buffers of a handle */
+int ems_debug_dump(ems_handle *h)
+{
+    if (!h) return EMS_EINVAL;
+#define D(x) fprintf(stderr, "  %-10s %p .. +%zu\n", #x, (void *)h->x.p, h->x.n * sizeof(*h->x.p))
+    D(d_app); D(d_ctov); D(d_decide); D(d_iters); D(d_synd); D(d_noisy); D(d_cw); D(d_nberr); D(d_lvl_ptr); D(d_lvl_cn);
+    D(d_cn_vn); D(d_cn_lh); D(d_i2b); D(d_b2i); D(d_t_vn); D(d_t_lh); D(d_t_pred); D(d_sched); D(d_scratch); D(d_stamps);
+#undef D
+    return EMS_OK;
+}
+
 /* developer diagnostics (EMS_STAMPS builds): zero / read the 16 per-phase cycle accumulators */
 int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset)
 {
@@ -586,6 +621,7 @@ int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (out16) HIP_TRY(hipMemcpy(out16, h->d_stamps.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out16) HIP_TRY(ems_debug_counters(out16 + 16, reset));   /* out16 really has 24 slots: 16 stamps + 8 counters */
     if (reset) HIP_TRY(hipMemset(h->d_stamps.p, 0, 16 * sizeof(unsigned long long)));
     return EMS_OK;
 }
@@ -660,7 +696,7 @@ int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *
     int8_t *ds = t.up(cs.tasks.data(), cs.tasks.size());
     if (!dcoef || !dg || !dl || !dout || !da || !db || !ds) return fail(EMS_ENOMEM, "device allocation failed");
     EmsPlan P{};
-    P.q = GF; P.dc = dc; P.nm = nm; P.nbOper = nbOper; P.offset = offset; P.nsteps = cs.nsteps; P.sched = ds;
+    P.q = GF; P.dc = dc; P.nm = nm; P.nbOper = nbOper; P.offset = offset; P.nsteps = cs.nsteps; (void)ds;
     P.n_lists = cs.n_lists; memcpy(P.out_list, cs.out_list, sizeof P.out_list);
     P.idx2bin = da; P.bin2idx = db;
     HIP_TRY(ems_launch_cn_unit(P, dcoef, dl, dg, dout, nullptr));

@@ -8,7 +8,7 @@
 
 int ems_lpe_for(int dc);                                     // lanes per edge row; 0 = unsupported degree
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
-size_t ems_wg_lds_bytes(int q, size_t wave_bytes, int waves);
+size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
@@ -26,3 +26,4 @@ hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide,
 hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
                                     const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st);
 hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_dev, int *s_gf_dev, hipStream_t st);
+hipError_t ems_debug_counters(unsigned long long *out8, int reset); // diagnostic builds (-DEMS_STAMPS) only

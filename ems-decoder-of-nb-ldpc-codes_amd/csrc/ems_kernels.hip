@@ -30,8 +30,11 @@ namespace {
 // accumulated per wave and added to P.stamps at kernel end.  Never compiled into the product.
 #ifdef EMS_STAMPS
 #define STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+__device__ unsigned long long g_dbg[8];
+#define DBG_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define DBG_ADD(i, v) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -363,7 +366,9 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     run(0, T1);
     if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    DBG_ADD(3, 1);
     if (__ballot(has && !done) != 0ull) {
+        DBG_ADD(4, 1);
         run(T1, nbOper);
         es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
     }
@@ -373,16 +378,31 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 // Forward/backward recursion + merges of CheckPassLogEMS (bubble_decoder.c:166-227) as a static task
 // table: step t runs P[t] = ES(P[t-1], in[t]), S[dc-1-t] = ES(S[dc-t], in[dc-1-t]) and every merge
 // ES(P[k], S[k+2]) whose operands became available after step t-1, side by side on 8-lane groups.
+// list ids inside one check-node visit: inputs 0..dc-1, prefixes P(k), suffixes S(k), merges M(k)
+__device__ __forceinline__ int list_P(int dc, int k) { return k == 0 ? 0 : dc + (k - 1); }
+__device__ __forceinline__ int list_S(int dc, int k) { return k == dc - 1 ? dc - 1 : dc + (dc - 2) + (k - 1); }
+__device__ __forceinline__ int list_M(int dc, int k) { return dc + 2 * (dc - 2) + k; }
+
 __device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane)
 {
     const int grp = lane >> 3;
+    const int dc = P.dc;
     const bool fast = P.nbOper <= ES_MAX_STEPS;
-    for (int t = 0; t < P.nsteps; ++t) {
+    for (int t = 1; t <= P.nsteps; ++t) {
+        // step t: forward P(t) = ES(P(t-1), in(t)); backward S(dc-1-t) = ES(S(dc-t), in(dc-1-t)); and the
+        // merges M(k) = ES(P(k), S(k+2)) that became ready after step t-1, lowest k first
+        const int k1 = t - 1, k2 = dc - 2 - t;
+        const bool v1 = k1 <= dc - 3 && 2 * k1 >= dc - 3;
+        const bool v2 = k2 >= 0 && k2 <= t - 1 && k2 != k1;
+        int ka = -1, kb = -1;
+        if (v1 && v2) { ka = min(k1, k2); kb = max(k1, k2); }
+        else if (v1) ka = k1;
+        else if (v2) ka = k2;
         int a = -1, b = -1, o = -1;
-        if (grp < 4) {
-            const int8_t *sc = P.sched + (t * 4 + grp) * 3;
-            a = sc[0]; b = sc[1]; o = sc[2];
-        }
+        if (grp == 0) { a = list_P(dc, t - 1); b = t; o = list_P(dc, t); }
+        else if (grp == 1) { a = list_S(dc, dc - t); b = dc - 1 - t; o = list_S(dc, dc - 1 - t); }
+        else if (grp == 2 && ka >= 0) { a = list_P(dc, ka); b = list_S(dc, ka + 2); o = list_M(dc, ka); }
+        else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
         if (fast) es_stage_fast(lists, lens, tbl, picks, P.q, lane, a, b, o, P.nm, P.nbOper);
         else es_stage(lists, lens, lane, a, b, o, P.nm, P.nbOper);
         wave_lds_sync();
@@ -565,10 +585,12 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                     T = nt;
                 }
             }
+            DBG_ADD(1, 1);
             if (__ballot(!done) == 0ull) break;
         }
     }
-    if (__ballot(!done) != 0ull) return false;
+    DBG_ADD(0, 1);
+    if (__ballot(!done) != 0ull) { DBG_ADD(2, 1); return false; }
 
     // ---- B ----
     int lc = 0;
@@ -629,8 +651,9 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 // One check-node visit by one wave: NB_LDPC.c:329-450 around bubble_decoder.c:72-305.
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
-__device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool first_sweep, const uint8_t *t_i2b,
-                                           const uint8_t *t_b2i, float *dense, EmsEntry *surv, EmsEntry *lists, int *lens, uint8_t *picks, int lane
+__device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int vn, int lh, bool first_sweep,
+                                           const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
+                                           EmsEntry *lists, int *lens, uint8_t *picks, int lane
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -644,21 +667,33 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
     const int nm = P.nm;
     const int qm1 = Q - 1;
     const int edge = cn * P.dc + t;
-    const int vn = P.cn_vn[edge];
-    const int lh = P.cn_lh[edge];
     float *app_row = P.app + ((size_t)f * P.N + vn) * Q;
     uint8_t *rec = P.ctov + ((size_t)f * P.E + edge) * P.rec_bytes;
     float *drow = dense + row * Q;
 
-    // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279) ----
+    // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279).
+    //      Every HBM read of the visit (APP row, record header, the nm record entries) is issued
+    //      before the first use, so the visit pays one memory round trip. ----
+    constexpr int NREC = (EMS_MAX_NM + LPE - 1) / LPE;
     float mvc[G::EPL];
     load_row<Q, LPE>(app_row, rl, mvc);
     if (!first_sweep) {
         const float dflt = *reinterpret_cast<const float *>(rec + 4 * nm);
         const int cnt = rec[4 * nm + 4];
+        float rv[NREC];
+        int rg[NREC];
+#pragma unroll
+        for (int c = 0; c < NREC; ++c) {
+            const int k = rl + c * LPE;
+            const int kk = k < nm ? k : 0;
+            rv[c] = reinterpret_cast<const float *>(rec)[kk];
+            rg[c] = rec[4 * nm + 5 + kk];
+        }
         fill_row<Q, LPE>(drow, rl, dflt);
         wave_lds_sync();
-        for (int k = rl; k < cnt; k += LPE) drow[rec[4 * nm + 5 + k]] = reinterpret_cast<const float *>(rec)[k];
+#pragma unroll
+        for (int c = 0; c < NREC; ++c)
+            if (rl + c * LPE < cnt) drow[rg[c]] = rv[c];
         wave_lds_sync();
         float c[G::EPL];
         load_row<Q, LPE>(drow, rl, c);
@@ -751,10 +786,23 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, bool
 
 // LDS carve of a workgroup: [idx2bin Q][bin2idx Q][first-nonzero-syndrome word, padded to 16] then one
 // region per wave: dense rows | lists | lens.
-template <int Q> __device__ __forceinline__ constexpr int wg_header_bytes() { return 2 * Q + 16; }
+// LDS carve of a workgroup: [idx2bin Q][bin2idx Q][first-nonzero-syndrome word, task counter, pad to 16]
+// [done flags, one byte per task, padded to 16] then one region per wave: dense rows | survivors | lists |
+// lens | picks.
+__host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16 + ((M + 15) & ~15); }
 
 // ------------------------------------------------------------------------------------------------
 // The decode kernel: one workgroup per frame, persistent over all sweeps.
+//
+// Inside a sweep the check nodes form a DAG (two check nodes depend on each other iff they share a
+// variable node; the earlier one in reference order goes first).  The host lists them in a topological
+// order (level by level) together with, per edge, the task index of the previous visitor of that
+// variable node in the same sweep.  Waves claim tasks in that order from an LDS counter, wait on the
+// one-byte done flags of their (at most dc) predecessors, run the visit and publish their own flag:
+// every APP row sees its visits in exactly the order of NB_LDPC.c:320, but no wave waits for a whole
+// level.  The smallest unfinished task never waits on anything unfinished, so the scheme cannot
+// deadlock; the spin is bounded anyway.  Sweeps are separated by __syncthreads() (Decision + Syndrom
+// need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
 __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
@@ -764,13 +812,18 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
     uint8_t *t_i2b = smem;
     uint8_t *t_b2i = smem + Q;
     unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
+    unsigned *next_task = first_bad + 1;
+    unsigned *spin_fail = first_bad + 2;
+    uint8_t *done = smem + 2 * Q + 16;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
     const int f = blockIdx.x;
+    const int rl = lane & (LPE - 1);
+    const int row = lane / LPE;
+    const int trow = row < P.dc ? row : P.dc - 1;
 
-    uint8_t *wbase = smem + wg_header_bytes<Q>() + (size_t)wave * P.wave_lds_bytes;
+    uint8_t *wbase = smem + wg_header_bytes(Q, P.M) + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
     constexpr int SURV_BYTES = G::NROWS * (SEL_CAP + LPE) * 8;       // survivor scratch of the selection
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
@@ -782,7 +835,8 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
         t_i2b[i] = P.idx2bin[i];
         t_b2i[i] = P.bin2idx[i];
     }
-    if (tid == 0) *first_bad = 0xFFFFFFFFu;
+    for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
 
 #ifdef EMS_STAMPS
@@ -792,18 +846,60 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
     int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
     unsigned synd = 0;
     for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
-        for (int lv = 0; lv < P.n_levels; ++lv) {              // NB_LDPC.c:320, level by level
-            const int b = P.lvl_ptr[lv], e = P.lvl_ptr[lv + 1];
-            for (int i = b + wave; i < e; i += nwaves)
-                process_cn<Q, LPE>(P, f, P.lvl_cn[i], sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
-#ifdef EMS_STAMPS
-                                   , st_acc, st_last
-#endif
-                );
-            STAMP(6);
-            __syncthreads();
-            STAMP(4);
+        const unsigned tag = (unsigned)(sweep + 1) & 0xFFu;
+        auto claim = [&]() {
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(next_task, 1u);
+            return (int)__builtin_amdgcn_readfirstlane((int)i);
+        };
+        int cur = claim();
+        int cn = 0, vn = 0, lh = 0, pred = -1;
+        if (cur < P.M) {
+            cn = P.t_cn[cur];
+            vn = P.t_vn[cur * P.dc + trow];
+            lh = P.t_lh[cur * P.dc + trow];
+            pred = P.t_pred[cur * P.dc + trow];
         }
+        while (cur < P.M) {                                    // NB_LDPC.c:320, in dependency order
+            // claim the following task now and fetch its descriptor under the current visit
+            const int nxt = claim();
+            int ncn = 0, nvn = 0, nlh = 0, npred = -1;
+            if (nxt < P.M) {
+                ncn = P.t_cn[nxt];
+                nvn = P.t_vn[nxt * P.dc + trow];
+                nlh = P.t_lh[nxt * P.dc + trow];
+                npred = P.t_pred[nxt * P.dc + trow];
+            }
+            // wait for the previous visitors of my variable nodes (same sweep)
+            {
+                const int pp = (rl == 0 && row < P.dc) ? pred : -1;
+                unsigned spins = 0;
+                for (;;) {
+                    const bool ok = pp < 0 || __hip_atomic_load(&done[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tag;
+                    if (__ballot(!ok) == 0ull) break;
+                    if (++spins > (1u << 24)) {                // never expected; keeps a bug from hanging the GPU
+                        if (lane == 0) atomicOr(spin_fail, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            STAMP(4);
+            process_cn<Q, LPE>(P, f, cn, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
+#ifdef EMS_STAMPS
+                               , st_acc, st_last
+#endif
+            );
+            // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cur = nxt; cn = ncn; vn = nvn; lh = nlh; pred = npred;
+        }
+        STAMP(6);
+        __syncthreads();
+        STAMP(4);
+        if (tid == 0) *next_task = 0;
         // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero
         //      sum; 0 iff codeword.  One thread per check node.
         for (int c = tid; c < P.M; c += blockDim.x) {
@@ -831,7 +927,7 @@ __global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
         for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[(wave < 9 ? 0 : 8) + i], st_acc[i]);
 #endif
     if (tid == 0) {
-        P.iters[f] = it;
+        P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
     }
 }
@@ -1025,11 +1121,11 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
     return dense + lists + lens + 5 * 64; // + pick bytes of the elementary steps
 }
 
-size_t ems_wg_lds_bytes(int q, size_t wave_bytes, int waves) { return (size_t)2 * q + 16 + wave_bytes * waves; }
+size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
 
 template <int Q, int LPE> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
 {
-    const size_t lds = ems_wg_lds_bytes(Q, P.wave_lds_bytes, P.waves_per_wg);
+    const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
     hipError_t e = set_max_lds(k_decode<Q, LPE>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_decode<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
@@ -1115,3 +1211,23 @@ hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_
     hipLaunchKernelGGL(k_sort_llr, dim3(N), dim3(64), (size_t)q * 4, st, app_dev, q, s_llr_dev, s_gf_dev);
     return hipGetLastError();
 }
+
+#ifdef EMS_STAMPS
+hipError_t ems_debug_counters(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z);
+    }
+    return e;
+}
+#else
+hipError_t ems_debug_counters(unsigned long long *out8, int reset)
+{
+    (void)reset;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    return hipSuccess;
+}
+#endif

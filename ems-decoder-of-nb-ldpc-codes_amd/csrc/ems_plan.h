@@ -38,9 +38,12 @@ struct EmsPlan {
     const int *lvl_cn;      // [M]
     const int *cn_vn;       // [M*dc] variable node of edge (cn*dc+i)      (code_t.mat)
     const uint8_t *cn_lh;   // [M*dc] log_alpha of the edge coefficient = index-1 (code_t.matValue)
-    // forward/backward/merge task table: [nsteps][4][3] = (in1 list, in2 list, out list) or -1
-    int nsteps;
-    const int8_t *sched;
+    // the same check nodes as a task list in dependency (level) order, for the dataflow scheduler
+    const int *t_cn;        // [M]    check node of task i
+    const int *t_vn;        // [M*dc] its variable nodes
+    const int *t_lh;        // [M*dc] log of its coefficients
+    const int *t_pred;      // [M*dc] task index of the previous visitor of that variable node in this sweep, or -1
+    int nsteps;             // dc-2 forward/backward steps
     int8_t out_list[16];    // list id holding the output for edge t
     int n_lists;
     // field tables

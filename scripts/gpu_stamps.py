@@ -19,9 +19,9 @@ for w in (sys.argv[1:] or ["gf256"]):
     dec = pkg.Decoder(code, nm, nop, 0.3, itmax, max_batch=B, early_exit=False)
     L = pkg.lib(); L.ems_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     dec.llr_init(noisy, sigma); dec.decode(B); dec.synchronize()
-    L.ems_debug_stamps(dec.h, None, 1)
+    L.ems_debug_stamps(dec.h, np.zeros(24, np.uint64).ctypes.data_as(C.c_void_p), 1)
     dec.llr_init(noisy, sigma); dec.decode(B); dec.synchronize()
-    st = np.zeros(16, np.uint64); L.ems_debug_stamps(dec.h, st.ctypes.data_as(C.c_void_p), 0)
+    st = np.zeros(24, np.uint64); L.ems_debug_stamps(dec.h, st.ctypes.data_as(C.c_void_p), 0)
     ms = dec.last_decode_ms
     print("%s B=%d decode %.2f ms (stamped build)" % (w, B, ms))
     for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
@@ -30,4 +30,6 @@ for w in (sys.argv[1:] or ["gf256"]):
     w0 = st[0:8].astype(np.float64); nw = min(9, dec and 9) * B
     per_wave_cycles = w0.sum() / nw
     print("  cycles per wave (waves 0-8 avg): %.3e ; => clock ~ %.2f GHz if the kernel took %.1f ms" % (per_wave_cycles, per_wave_cycles / (ms * 1e-3) / 1e9, ms))
+    d = st[16:24].astype(np.float64)
+    print("  selections(wave) %d, threshold iterations/selection %.2f, slow-path fraction %.4f; ES stages %d, continuation fraction %.4f" % (d[0], d[1] / max(d[0], 1), d[2] / max(d[0], 1), d[3], d[4] / max(d[3], 1)))
     dec.close()
