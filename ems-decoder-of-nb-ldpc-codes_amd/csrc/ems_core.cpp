@@ -217,7 +217,9 @@ int refresh_plan(ems_handle *h)
     P.wave_lds_bytes = (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
     int widest = 1;
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-    int waves = std::min(16, widest);
+    const int wcap = ems_max_waves_for(h->dc);
+    int waves = std::min(wcap, widest);
+    if (const char *ew = getenv("EMS_WAVES")) waves = std::max(1, std::min(wcap, atoi(ew)));   // developer knob
     const size_t lds_cap = 160 * 1024;
     while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
     if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");

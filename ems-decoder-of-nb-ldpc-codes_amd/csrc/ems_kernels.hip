@@ -31,7 +31,11 @@ namespace {
 #ifdef EMS_STAMPS
 #define STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
 __device__ unsigned long long g_dbg[8];
+#ifdef EMS_COUNTERS
 #define DBG_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define DBG_ADD(i, v) do { } while (0)
+#endif
 #else
 #define STAMP(i) do { } while (0)
 #define DBG_ADD(i, v) do { } while (0)
@@ -805,7 +809,7 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
-__global__ void __launch_bounds__(1024) k_decode(const EmsPlan P)
+__global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1110,6 +1114,9 @@ template <typename T> hipError_t set_max_lds(T kernel, size_t bytes)
 // host-side launchers
 // ================================================================================================
 int ems_lpe_for(int dc) { return dc <= 4 ? 16 : (dc <= 8 ? 8 : 0); }
+// waves per workgroup the decode kernel is compiled for: the dc <= 4 kernels keep q/16 values per lane in
+// registers and need the 170-VGPR budget of 12 waves; the dc <= 8 kernels fit the 128 of 16 waves
+int ems_max_waves_for(int dc) { return ems_lpe_for(dc) == 8 ? 16 : 12; }
 
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {

@@ -27,8 +27,10 @@ for w in (sys.argv[1:] or ["gf256"]):
     for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
         tot = float(st[grp:grp + 8].sum()) or 1.0
         print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(7)))
-    w0 = st[0:8].astype(np.float64); nw = min(9, dec and 9) * B
+    w0 = st[0:8].astype(np.float64); nw = int(os.environ.get("EMS_WAVES", "9")) * B if os.environ.get("EMS_WAVES") else 9 * B
     per_wave_cycles = w0.sum() / nw
+    visits = code.M * (itmax - 1) * B
+    print("  cycles per visit by phase: " + ", ".join("%s %.0f" % (names[i], float(st[i] + st[8 + i]) / visits) for i in range(7)))
     print("  cycles per wave (waves 0-8 avg): %.3e ; => clock ~ %.2f GHz if the kernel took %.1f ms" % (per_wave_cycles, per_wave_cycles / (ms * 1e-3) / 1e9, ms))
     d = st[16:24].astype(np.float64)
     print("  selections(wave) %d, threshold iterations/selection %.2f, slow-path fraction %.4f; ES stages %d, continuation fraction %.4f" % (d[0], d[1] / max(d[0], 1), d[2] / max(d[0], 1), d[3], d[4] / max(d[3], 1)))
