@@ -123,6 +123,10 @@ __device__ __forceinline__ int gf_div_log(int g, int lh, int qm1)   // DIVGF[g][
     return g == 0 ? 0 : x + 1;
 }
 
+// Every message list in LDS has nm entries followed by two (+inf, invalid) pads, so that a competitor
+// walking off its list needs no bounds test: the pad makes its head +inf and it never wins again.
+__host__ __device__ inline int list_stride(int nm) { return nm + 2; }
+
 __device__ __forceinline__ unsigned sym_comb(unsigned a, unsigned b)
 {
     return ((a ^ b) & 0xFFu) | ((a | b) & EMS_S_INVALID);
@@ -141,12 +145,13 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
 {
     const int p = lane & 7;
     const bool has = o_id >= 0;
-    const EmsEntry *in1 = lists + (has ? a_id : 0) * nm;
-    const EmsEntry *in2 = lists + (has ? b_id : 0) * nm;
-    EmsEntry *out = lists + (has ? o_id : 0) * nm;
+    const int nmp = list_stride(nm);
+    const EmsEntry *in1 = lists + (has ? a_id : 0) * nmp;
+    const EmsEntry *in2 = lists + (has ? b_id : 0) * nmp;
+    EmsEntry *out = lists + (has ? o_id : 0) * nmp;
 
     if (has)
-        for (int k = p; k < nm; k += 8) out[k] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID}; // :370-374
+        for (int k = p; k < nmp; k += 8) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
 
     const bool rowc = p < 4;
     const EmsEntry *mv = rowc ? in2 : in1;
@@ -208,7 +213,7 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
 // Values inside the check node are non-negative floats (normalised inputs and their sums), so the
 // IEEE order equals the unsigned order of the bit patterns; the loop compares bit patterns.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned SENT_BITS = 0x47C35000u; // bit pattern of 1e5f
+// (bit pattern of 1e5f is 0x47C35000)
 constexpr int ES_MAX_STEPS = 64;
 
 __device__ __forceinline__ unsigned red8_minu(unsigned x)
@@ -323,6 +328,39 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     return (base >= nm) || stopped || (T >= nbOper);
 }
 
+__device__ __forceinline__ int red8_sumi(int x)
+{
+    x += dpp_i<DPP_XOR1>(x);
+    x += dpp_i<DPP_XOR2>(x);
+    x += dpp_i<DPP_HMIRROR>(x);
+    return x;
+}
+
+// Merge loops.  A single wave executes a dependent instruction stream at ~7 cycles per instruction, and
+// the visit latency -- not throughput -- bounds the decoder (the layered schedule is a 441-deep chain per
+// sweep), so the loop is pared down to the bone:
+//   SPECULATIVE form (12 VALU/LDS instructions per step): the winner of a step is every lane whose head
+//   equals the group minimum -- exactly one lane unless two heads tie.  A tie makes two lanes advance, so
+//   it shows up as (sum of advances over the group) != (number of steps); the stage is then redone in the
+//   EXACT form, where the winner is the lowest competitor among the equal heads (bubble_decoder.c:47).
+// Both rely on the caller's guard: every valid value in the visit is in [0, 1e4), hence (a) float order ==
+// unsigned order of the bit patterns and (b) a head >= 1e5 always involves an invalid (padded) entry, so
+// whichever such head is taken the step is the "source index -1 -> break" stop of bubble_decoder.c:478.
+template <bool EXACT>
+__device__ __forceinline__ void es_merge(unsigned &hv, int &pos, float &nxv, float fxv, const EmsEntry *mv, uint8_t *pk,
+                                         uint8_t *dummy, int p, int gbase, int from, int to)
+{
+    for (int ss = from; ss < to; ++ss) {
+        const unsigned m = red8_minu(hv);
+        bool iw = (hv == m);
+        if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
+        *(iw ? pk + ss : dummy) = (uint8_t)(p | (pos << 3));
+        pos += iw ? 1 : 0;
+        hv = iw ? (unsigned)__float_as_int(fxv + nxv) : hv;
+        nxv = mv[pos + 1].v;
+    }
+}
+
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
                                               int lane, int a_id, int b_id, int o_id, int nm, int nbOper)
 {
@@ -330,68 +368,60 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     const int gbase = lane & ~7;
     const int gsel = (lane >> 3) & 3;
     const bool has = o_id >= 0;
-    const EmsEntry *in1 = lists + (has ? a_id : 0) * nm;
-    const EmsEntry *in2 = lists + (has ? b_id : 0) * nm;
-    EmsEntry *out = lists + (has ? o_id : 0) * nm;
+    const int nmp = list_stride(nm);
+    const EmsEntry *in1 = lists + (has ? a_id : 0) * nmp;
+    const EmsEntry *in2 = lists + (has ? b_id : 0) * nmp;
+    EmsEntry *out = lists + (has ? o_id : 0) * nmp;
     unsigned *tbl = tbl_base + gsel * q;
-    uint8_t *picks = picks_base + gsel * ES_MAX_STEPS;
-    uint8_t *dummy = picks_base + 4 * ES_MAX_STEPS + lane;
+    uint8_t *picks = picks_base + (lane >> 3) * ES_MAX_STEPS;    // 8 areas: lanes without a task scribble in theirs
+    uint8_t *dummy = picks_base + 8 * ES_MAX_STEPS + lane;
 
     if (has)
-        for (int k = p; k < nm; k += 8) out[k] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID}; // :370-374
+        for (int k = p; k < nmp; k += 8) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
 
     const bool rowc = p < 4;
     const EmsEntry *mv = rowc ? in2 : in1;
-    int pos = rowc ? 0 : 4;
+    const int pos0 = rowc ? 0 : 4;
     const float fxv = rowc ? in1[p].v : in2[p - 4].v;
-    unsigned hv = (unsigned)__float_as_int(fxv + mv[pos].v);
-    float nxv = mv[min(pos + 1, nm - 1)].v;
-
-    auto run = [&](int from, int to) {
-        for (int ss = from; ss < to; ++ss) {
-            const unsigned m = red8_minu(hv);                       // minimum(): smallest head ...
-            const unsigned long long eqb = __ballot(hv == m);
-            int wp = __ffs((unsigned)(eqb >> gbase)) - 1;           // ... first competitor holding it
-            wp = (m < SENT_BITS) ? wp : 0;                          // nothing below 1e5 -> competitor 0
-            const bool iw = has && (p == wp);
-            *(iw ? picks + ss : dummy) = (uint8_t)(p | (pos << 3));
-            const int posn = pos + (iw ? 1 : 0);
-            unsigned nh = (unsigned)__float_as_int(fxv + nxv);
-            nh = posn < nm ? nh : 0xFFFFFFFFu;                      // walked off the list: never wins again
-            hv = iw ? nh : hv;
-            pos = posn;
-            nxv = mv[min(pos + 1, nm - 1)].v;
-        }
+    unsigned hv;
+    int pos;
+    float nxv;
+    auto init = [&]() {
+        pos = pos0;
+        hv = (unsigned)__float_as_int(fxv + mv[pos0].v);         // tab_aux[r][c] = In1[r] + In2[c]
+        nxv = mv[pos0 + 1].v;
     };
 
     int S = 0;
     bool done;
     const int T1 = min(nbOper, nm + 3);
-    run(0, T1);
+    init();
+    es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+    if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
+        init();
+        es_merge<true>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+    }
     if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
-    DBG_ADD(3, 1);
     if (__ballot(has && !done) != 0ull) {
-        DBG_ADD(4, 1);
-        run(T1, nbOper);
+        // rare: neither nm outputs nor a stop within the first nm+3 picks -> merge on up to nbOper
+        es_merge<true>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, T1, nbOper);
         es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
     }
     if (has && p == 0) lens[o_id] = S;
 }
 
-// Forward/backward recursion + merges of CheckPassLogEMS (bubble_decoder.c:166-227) as a static task
-// table: step t runs P[t] = ES(P[t-1], in[t]), S[dc-1-t] = ES(S[dc-t], in[dc-1-t]) and every merge
-// ES(P[k], S[k+2]) whose operands became available after step t-1, side by side on 8-lane groups.
 // list ids inside one check-node visit: inputs 0..dc-1, prefixes P(k), suffixes S(k), merges M(k)
 __device__ __forceinline__ int list_P(int dc, int k) { return k == 0 ? 0 : dc + (k - 1); }
 __device__ __forceinline__ int list_S(int dc, int k) { return k == dc - 1 ? dc - 1 : dc + (dc - 2) + (k - 1); }
 __device__ __forceinline__ int list_M(int dc, int k) { return dc + 2 * (dc - 2) + k; }
 
-__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane)
+__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane,
+                                        bool literal)
 {
     const int grp = lane >> 3;
     const int dc = P.dc;
-    const bool fast = P.nbOper <= ES_MAX_STEPS;
+    const bool fast = !literal && P.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= P.nsteps; ++t) {
         // step t: forward P(t) = ES(P(t-1), in(t)); backward S(dc-1-t) = ES(S(dc-t), in(dc-1-t)); and the
         // merges M(k) = ES(P(k), S(k+2)) that became ready after step t-1, lowest k first
@@ -546,7 +576,7 @@ template <int LPE> __device__ __forceinline__ int row_excl_scan_i(int x, int rl)
 
 template <int Q, int LPE>
 __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
-                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact)
+                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big)
 {
     using G = Geo<Q, LPE>;
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
@@ -644,9 +674,12 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
             const float v = ok ? my[k].v : EMS_SENTINEL;
             const int g = ok ? (int)my[k].s : 0;
             const int gi = gf_mul_log(g, lh, Q - 1);
-            inl[rank[k]] = EmsEntry{rank[k] == 0 ? 0.0f : v - v0, (unsigned)t_i2b[gi]};
+            const float nv = rank[k] == 0 ? 0.0f : v - v0;
+            big = big || !(nv < 1e4f);
+            inl[rank[k]] = EmsEntry{nv, (unsigned)t_i2b[gi]};
         }
     }
+    if (rowact && rl < 2) inl[nm + rl] = EmsEntry{__builtin_inff(), EMS_S_INVALID};   // list pads
     (void)lane;
     return true;
 }
@@ -707,12 +740,14 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
 
     STAMP(0);
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
-    EmsEntry *inl = lists + t * nm;
+    const int nmp = list_stride(nm);
+    EmsEntry *inl = lists + t * nmp;
+    bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
 #ifdef EMS_ABLATE_SEL
     for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
     if (false)
 #endif
-    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
@@ -725,6 +760,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
             const EmsEntry r = inl[k < nm ? k : 0];
             const int gi = gf_mul_log((int)r.s, lh, qm1);
             tmp[c] = EmsEntry{k == 0 ? 0.0f : r.v - v0, (unsigned)t_i2b[gi]};
+            big = big || (k < nm && !(tmp[c].v < 1e4f));
         }
         wave_lds_sync();
 #pragma unroll
@@ -732,13 +768,14 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
             const int k = rl + c * LPE;
             if (rowact && k < nm) inl[k] = tmp[c];
         }
+        if (rowact && rl < 2) inl[nm + rl] = EmsEntry{__builtin_inff(), EMS_S_INVALID};
     }
     wave_lds_sync();
 
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
 #ifndef EMS_ABLATE_ES
-    cn_core(P, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane);
+    cn_core(P, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane, __ballot(big) != 0ull);
 #else
     if (lane < 16) lens[lane < P.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
     wave_lds_sync();
@@ -748,7 +785,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
     const int oid = P.out_list[t];
-    const EmsEntry *ol = lists + oid * nm;
+    const EmsEntry *ol = lists + oid * nmp;
     const int stp = (P.dc == 2) ? nm : lens[oid];
     const float dflt = ol[stp - 1].v + P.offset;
     fill_row<Q, LPE>(drow, rl, dflt);
@@ -832,8 +869,8 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
     constexpr int SURV_BYTES = G::NROWS * (SEL_CAP + LPE) * 8;       // survivor scratch of the selection
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
-    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((P.n_lists * P.nm * 8 + 15) & ~15));
-    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((P.n_lists * 4 + 15) & ~15);   // 4 x 64 pick bytes + 64 dummies
+    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((P.n_lists * list_stride(P.nm) * 8 + 15) & ~15));
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((P.n_lists * 4 + 15) & ~15);   // 8 x 64 pick bytes + 64 dummies
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
@@ -1023,22 +1060,30 @@ __global__ void k_expand_ctov(const uint8_t *__restrict__ rec_base, int rec_byte
 __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, const int *idx2, float *out,
                           int *idxout, int nm, int nbOper, int q, const uint8_t *idx2bin, const uint8_t *bin2idx)
 {
-    __shared__ EmsEntry lists[3 * EMS_MAX_NM];
+    __shared__ EmsEntry lists[3 * (EMS_MAX_NM + 2)];
     __shared__ int lens[4];
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
-    __shared__ uint8_t picks[5 * 64];
+    __shared__ uint8_t picks[9 * 64];
     const int lane = threadIdx.x;
-    for (int k = lane; k < nm; k += 64) {
-        lists[k] = EmsEntry{in1[k], idx1[k] < 0 ? EMS_S_INVALID : (unsigned)idx2bin[idx1[k]]};
-        lists[nm + k] = EmsEntry{in2[k], idx2[k] < 0 ? EMS_S_INVALID : (unsigned)idx2bin[idx2[k]]};
+    const int nmp = list_stride(nm);
+    bool big = false;
+    for (int k = lane; k < nmp; k += 64) {
+        const bool pad = k >= nm;
+        const float v1 = pad ? __builtin_inff() : in1[k], v2 = pad ? __builtin_inff() : in2[k];
+        const bool i1 = pad || idx1[k] < 0, i2 = pad || idx2[k] < 0;
+        lists[k] = EmsEntry{v1, i1 ? EMS_S_INVALID : (unsigned)idx2bin[idx1[k]]};
+        lists[nmp + k] = EmsEntry{v2, i2 ? EMS_S_INVALID : (unsigned)idx2bin[idx2[k]]};
+        big = big || (!i1 && !(v1 >= 0.0f && v1 < 1e4f)) || (!i2 && !(v2 >= 0.0f && v2 < 1e4f));
     }
     wave_lds_sync();
     const bool g0 = lane < 8;
-    if (nbOper <= ES_MAX_STEPS) es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+    // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
+    if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
+        es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
     else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
-        const EmsEntry e = lists[2 * nm + k];
+        const EmsEntry e = lists[2 * nmp + k];
         out[k] = e.v;
         idxout[k] = (e.s & EMS_S_INVALID) ? -1 : (int)bin2idx[e.s & 0xFFu];
     }
@@ -1048,22 +1093,29 @@ template <int Q>
 __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int nm = P.nm, dc = P.dc, nmp = list_stride(P.nm);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(smem);
-    int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * P.nm * 8 + 15) & ~15));
+    int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * nmp * 8 + 15) & ~15));
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
-    __shared__ uint8_t picks[5 * 64];
+    __shared__ uint8_t picks[9 * 64];
     const int lane = threadIdx.x;
-    const int nm = P.nm, dc = P.dc;
-    for (int i = lane; i < dc * nm; i += 64) {                 // rotation, bubble_decoder.c:133-152
-        const int t = i / nm;
-        const int g = vtoc_gf[i];
-        lists[i] = EmsEntry{vtoc_llr[i], g < 0 ? EMS_S_INVALID : (unsigned)P.idx2bin[gf_mul_log(g, coef[t] - 1, Q - 1)]};
+    bool big = false;
+    for (int i = lane; i < dc * nmp; i += 64) {                // rotation, bubble_decoder.c:133-152
+        const int t = i / nmp, k = i - t * nmp;
+        if (k >= nm) {
+            lists[i] = EmsEntry{__builtin_inff(), EMS_S_INVALID};
+        } else {
+            const int g = vtoc_gf[t * nm + k];
+            const float v = vtoc_llr[t * nm + k];
+            lists[i] = EmsEntry{v, g < 0 ? EMS_S_INVALID : (unsigned)P.idx2bin[gf_mul_log(g, coef[t] - 1, Q - 1)]};
+            big = big || (g >= 0 && !(v >= 0.0f && v < 1e4f));
+        }
     }
     wave_lds_sync();
-    cn_core(P, lists, lens, tbl, picks, lane);
+    cn_core(P, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
-        const EmsEntry *ol = lists + oid * nm;
+        const EmsEntry *ol = lists + oid * nmp;
         const int stp = (dc == 2) ? nm : lens[oid];
         const float dflt = ol[stp - 1].v + P.offset;
         for (int g = lane; g < Q; g += 64) ctov[t * Q + g] = dflt;
@@ -1123,9 +1175,9 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
     const int lpe = ems_lpe_for(dc);
     if (!lpe) return 0;
     const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * (32 + lpe) * 8; // staging rows + survivor scratch
-    const size_t lists = ((size_t)n_lists * nm * 8 + 15) & ~(size_t)15;
+    const size_t lists = ((size_t)n_lists * list_stride(nm) * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens + 5 * 64; // + pick bytes of the elementary steps
+    return dense + lists + lens + 9 * 64; // + pick bytes of the elementary steps
 }
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
@@ -1191,7 +1243,7 @@ hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx
 hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov,
                               hipStream_t st)
 {
-    const size_t lds = (((size_t)P.n_lists * P.nm * 8 + 15) & ~(size_t)15) + (((size_t)P.n_lists * 4 + 15) & ~(size_t)15);
+    const size_t lds = (((size_t)P.n_lists * list_stride(P.nm) * 8 + 15) & ~(size_t)15) + (((size_t)P.n_lists * 4 + 15) & ~(size_t)15);
     if (P.q == 256) hipLaunchKernelGGL((k_cn_unit<256>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
     else if (P.q == 64) hipLaunchKernelGGL((k_cn_unit<64>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
     else if (P.q == 16) hipLaunchKernelGGL((k_cn_unit<16>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
