@@ -362,7 +362,7 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &pos, float &nxv, flo
 }
 
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
-                                              int lane, int a_id, int b_id, int o_id, int nm, int nbOper)
+                                              int lane, int a_id, int b_id, int o_id, int nm, int nbOper, int T1)
 {
     const int p = lane & 7;
     const int gbase = lane & ~7;
@@ -376,8 +376,10 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     uint8_t *picks = picks_base + (lane >> 3) * ES_MAX_STEPS;    // 8 areas: lanes without a task scribble in theirs
     uint8_t *dummy = picks_base + 8 * ES_MAX_STEPS + lane;
 
-    if (has)
+    if (has) {
+#pragma unroll 5
         for (int k = p; k < nmp; k += 8) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
+    }
 
     const bool rowc = p < 4;
     const EmsEntry *mv = rowc ? in2 : in1;
@@ -394,13 +396,19 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 
     int S = 0;
     bool done;
-    const int T1 = min(nbOper, nm + 3);
     init();
     es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+#ifdef EMS_DUP_LOOP   /* timing experiment: the merge loop twice (same result) */
+    init();
+    es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+#endif
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
         init();
         es_merge<true>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
     }
+#ifdef EMS_DUP_POST   /* timing experiment: the post-pass twice (idempotent) */
+    if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+#endif
     if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
@@ -411,18 +419,26 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     if (has && p == 0) lens[o_id] = S;
 }
 
+// Decoder parameters as the device functions see them.  In the specialised kernel instantiations
+// (template DC, NM > 0) dc, nm and the first-pass length T1 are compile-time constants after inlining, so
+// the small loops over list entries unroll and most of the scalar bookkeeping folds away.
+struct Cfg {
+    int dc, nm, nbOper, T1, q, nsteps, n_lists;
+    float offset;
+};
+
 // list ids inside one check-node visit: inputs 0..dc-1, prefixes P(k), suffixes S(k), merges M(k)
 __device__ __forceinline__ int list_P(int dc, int k) { return k == 0 ? 0 : dc + (k - 1); }
 __device__ __forceinline__ int list_S(int dc, int k) { return k == dc - 1 ? dc - 1 : dc + (dc - 2) + (k - 1); }
 __device__ __forceinline__ int list_M(int dc, int k) { return dc + 2 * (dc - 2) + k; }
 
-__device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane,
+__device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane,
                                         bool literal)
 {
     const int grp = lane >> 3;
-    const int dc = P.dc;
-    const bool fast = !literal && P.nbOper <= ES_MAX_STEPS;
-    for (int t = 1; t <= P.nsteps; ++t) {
+    const int dc = C.dc;
+    const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
+    for (int t = 1; t <= C.nsteps; ++t) {
         // step t: forward P(t) = ES(P(t-1), in(t)); backward S(dc-1-t) = ES(S(dc-t), in(dc-1-t)); and the
         // merges M(k) = ES(P(k), S(k+2)) that became ready after step t-1, lowest k first
         const int k1 = t - 1, k2 = dc - 2 - t;
@@ -437,8 +453,8 @@ __device__ __forceinline__ void cn_core(const EmsPlan &P, EmsEntry *lists, int *
         else if (grp == 1) { a = list_S(dc, dc - t); b = dc - 1 - t; o = list_S(dc, dc - 1 - t); }
         else if (grp == 2 && ka >= 0) { a = list_P(dc, ka); b = list_S(dc, ka + 2); o = list_M(dc, ka); }
         else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
-        if (fast) es_stage_fast(lists, lens, tbl, picks, P.q, lane, a, b, o, P.nm, P.nbOper);
-        else es_stage(lists, lens, lane, a, b, o, P.nm, P.nbOper);
+        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, a, b, o, C.nm, C.nbOper, C.T1);
+        else es_stage(lists, lens, lane, a, b, o, C.nm, C.nbOper);
         wave_lds_sync();
     }
 }
@@ -688,7 +704,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 // One check-node visit by one wave: NB_LDPC.c:329-450 around bubble_decoder.c:72-305.
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE>
-__device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int vn, int lh, bool first_sweep,
+__device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
                                            EmsEntry *lists, int *lens, uint8_t *picks, int lane
 #ifdef EMS_STAMPS
@@ -699,11 +715,11 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
     using G = Geo<Q, LPE>;
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
-    const bool rowact = row < P.dc;
-    const int t = rowact ? row : P.dc - 1;         // idle rows shadow the last edge, stores masked
-    const int nm = P.nm;
+    const bool rowact = row < C.dc;
+    const int t = rowact ? row : C.dc - 1;         // idle rows shadow the last edge, stores masked
+    const int nm = C.nm;
     const int qm1 = Q - 1;
-    const int edge = cn * P.dc + t;
+    const int edge = cn * C.dc + t;
     float *app_row = P.app + ((size_t)f * P.N + vn) * Q;
     uint8_t *rec = P.ctov + ((size_t)f * P.E + edge) * P.rec_bytes;
     float *drow = dense + row * Q;
@@ -775,9 +791,9 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
 #ifndef EMS_ABLATE_ES
-    cn_core(P, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane, __ballot(big) != 0ull);
+    cn_core(C, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane, __ballot(big) != 0ull);
 #else
-    if (lane < 16) lens[lane < P.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
+    if (lane < 16) lens[lane < C.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
     wave_lds_sync();
 #endif
 
@@ -786,8 +802,8 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, int f, int cn, int 
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
     const int oid = P.out_list[t];
     const EmsEntry *ol = lists + oid * nmp;
-    const int stp = (P.dc == 2) ? nm : lens[oid];
-    const float dflt = ol[stp - 1].v + P.offset;
+    const int stp = (C.dc == 2) ? nm : lens[oid];
+    const float dflt = ol[stp - 1].v + C.offset;
     fill_row<Q, LPE>(drow, rl, dflt);
     wave_lds_sync();
     for (int k = rl; k < stp; k += LPE) {
@@ -845,10 +861,19 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // deadlock; the spin is bounded anyway.  Sweeps are separated by __syncthreads() (Decision + Syndrom
 // need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
-template <int Q, int LPE>
+template <int Q, int LPE, int DC, int NM>
 __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
+    Cfg C;
+    C.dc = DC > 0 ? DC : P.dc;
+    C.nm = NM > 0 ? NM : P.nm;
+    C.nbOper = P.nbOper;
+    C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
+    C.q = Q;
+    C.nsteps = C.dc - 2;
+    C.n_lists = C.dc + 3 * (C.dc - 2);
+    C.offset = P.offset;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *t_i2b = smem;
     uint8_t *t_b2i = smem + Q;
@@ -862,15 +887,15 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
     const int f = blockIdx.x;
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
-    const int trow = row < P.dc ? row : P.dc - 1;
+    const int trow = row < C.dc ? row : C.dc - 1;
 
     uint8_t *wbase = smem + wg_header_bytes(Q, P.M) + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
     constexpr int SURV_BYTES = G::NROWS * (SEL_CAP + LPE) * 8;       // survivor scratch of the selection
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
-    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((P.n_lists * list_stride(P.nm) * 8 + 15) & ~15));
-    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((P.n_lists * 4 + 15) & ~15);   // 8 x 64 pick bytes + 64 dummies
+    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((C.n_lists * 4 + 15) & ~15);   // 8 x 64 pick bytes + 64 dummies
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
@@ -897,9 +922,9 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
         int cn = 0, vn = 0, lh = 0, pred = -1;
         if (cur < P.M) {
             cn = P.t_cn[cur];
-            vn = P.t_vn[cur * P.dc + trow];
-            lh = P.t_lh[cur * P.dc + trow];
-            pred = P.t_pred[cur * P.dc + trow];
+            vn = P.t_vn[cur * C.dc + trow];
+            lh = P.t_lh[cur * C.dc + trow];
+            pred = P.t_pred[cur * C.dc + trow];
         }
         while (cur < P.M) {                                    // NB_LDPC.c:320, in dependency order
             // claim the following task now and fetch its descriptor under the current visit
@@ -907,13 +932,13 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
             int ncn = 0, nvn = 0, nlh = 0, npred = -1;
             if (nxt < P.M) {
                 ncn = P.t_cn[nxt];
-                nvn = P.t_vn[nxt * P.dc + trow];
-                nlh = P.t_lh[nxt * P.dc + trow];
-                npred = P.t_pred[nxt * P.dc + trow];
+                nvn = P.t_vn[nxt * C.dc + trow];
+                nlh = P.t_lh[nxt * C.dc + trow];
+                npred = P.t_pred[nxt * C.dc + trow];
             }
             // wait for the previous visitors of my variable nodes (same sweep)
             {
-                const int pp = (rl == 0 && row < P.dc) ? pred : -1;
+                const int pp = (rl == 0 && row < C.dc) ? pred : -1;
                 unsigned spins = 0;
                 for (;;) {
                     const bool ok = pp < 0 || __hip_atomic_load(&done[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tag;
@@ -927,7 +952,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, f, cn, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
+            process_cn<Q, LPE>(P, C, f, cn, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
@@ -945,8 +970,8 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
         //      sum; 0 iff codeword.  One thread per check node.
         for (int c = tid; c < P.M; c += blockDim.x) {
             unsigned acc = 0;
-            for (int i = 0; i < P.dc; ++i) {
-                const int ed = c * P.dc + i;
+            for (int i = 0; i < C.dc; ++i) {
+                const int ed = c * C.dc + i;
                 const int x = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
                 acc ^= t_i2b[gf_mul_log(x, P.cn_lh[ed], Q - 1)];
             }
@@ -1079,7 +1104,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     const bool g0 = lane < 8;
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
     if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
-        es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+        es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper, min(nbOper, nm + 3));
     else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
@@ -1112,7 +1137,10 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
         }
     }
     wave_lds_sync();
-    cn_core(P, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
+    Cfg C;
+    C.dc = dc; C.nm = nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, nm + 3); C.q = Q; C.nsteps = dc - 2;
+    C.n_lists = P.n_lists; C.offset = P.offset;
+    cn_core(C, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
         const EmsEntry *ol = lists + oid * nmp;
@@ -1182,18 +1210,23 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
 
-template <int Q, int LPE> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
+template <int Q, int LPE, int DC = 0, int NM = 0> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
 {
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode<Q, LPE>, lds);
+    hipError_t e = set_max_lds(k_decode<Q, LPE, DC, NM>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_decode<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipLaunchKernelGGL((k_decode<Q, LPE, DC, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
 
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
 {
     const int lpe = ems_lpe_for(P.dc);
+    // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
+    const bool spec_ok = P.nbOper >= P.nm + 3 && P.nbOper <= 64;
+    if (spec_ok && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);
+    if (spec_ok && P.q == 64 && P.dc == 4 && P.nm == 16) return launch_decode_t<64, 16, 4, 16>(P, B, st);
+    if (spec_ok && P.q == 16 && P.dc == 8 && P.nm == 8) return launch_decode_t<16, 8, 8, 8>(P, B, st);
     if (lpe == 16) {
         if (P.q == 256) return launch_decode_t<256, 16>(P, B, st);
         if (P.q == 64) return launch_decode_t<64, 16>(P, B, st);
