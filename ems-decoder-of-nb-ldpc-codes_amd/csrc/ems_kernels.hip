@@ -674,13 +674,21 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         *reinterpret_cast<unsigned long long *>(&surv[idx]) = key[k];   // mono keys; slots >= cnt get the max key
     }
     wave_lds_sync();
-    int cmax = 0;
+    // all SEL_CAP slots hold a key (slots >= cnt the maximal one), so the rank loop has a fixed trip count;
+    // the keys are fetched four at a time so that the LDS latency is paid once per batch, not per key
 #pragma unroll
-    for (int r = 0; r < G::NROWS; ++r) cmax = max(cmax, __builtin_amdgcn_readlane(cnt, r * LPE));
-    for (int j = 0; j < cmax; ++j) {
-        const unsigned long long kj = *reinterpret_cast<const unsigned long long *>(&surv[j]);
+    for (int j0 = 0; j0 < (Q < SEL_CAP ? Q : SEL_CAP); j0 += 4) {
+        unsigned long long kj[4];
 #pragma unroll
-        for (int k = 0; k < SPL; ++k) rank[k] += (kj < key[k]) ? 1 : 0;
+        for (int u = 0; u < 4; u += 2) {
+            const uint4 two = *reinterpret_cast<const uint4 *>(&surv[j0 + u]);
+            kj[u] = ((unsigned long long)two.y << 32) | two.x;
+            kj[u + 1] = ((unsigned long long)two.w << 32) | two.z;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) rank[k] += (kj[u] < key[k]) ? 1 : 0;
     }
     const float v0 = rmin < EMS_SENTINEL ? rmin : EMS_SENTINEL;         // the first selected value
 #pragma unroll
