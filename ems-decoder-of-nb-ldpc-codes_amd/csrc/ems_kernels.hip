@@ -398,9 +398,27 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     bool done;
     init();
     es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
-#ifdef EMS_DUP_LOOP   /* timing experiment: the merge loop twice (same result) */
-    init();
-    es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+#ifdef EMS_DUP_LOOP   /* timing experiment: the merge loop twice (the 2nd run's picks are discarded) */
+    {
+        const unsigned hv_s = hv; const int pos_s = pos; const float nxv_s = nxv;
+        init();
+        for (int ss = 0; ss < T1; ++ss) {
+            const unsigned m = red8_minu(hv);
+            const bool iw = (hv == m);
+#if EMS_DUP_LOOP != 2
+            *(iw ? dummy : dummy) = (uint8_t)(p | (pos << 3));
+#endif
+            pos += iw ? 1 : 0;
+            hv = iw ? (unsigned)__float_as_int(fxv + nxv) : hv;
+#if EMS_DUP_LOOP != 3
+            nxv = mv[pos + 1].v;
+#else
+            nxv = nxv + 1.0f;
+#endif
+        }
+        asm volatile("" :: "v"(hv), "v"(pos), "v"(nxv));
+        hv = hv_s; pos = pos_s; nxv = nxv_s;
+    }
 #endif
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
         init();
@@ -454,6 +472,10 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
         else if (grp == 2 && ka >= 0) { a = list_P(dc, ka); b = list_S(dc, ka + 2); o = list_M(dc, ka); }
         else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
         if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, a, b, o, C.nm, C.nbOper, C.T1);
+#ifdef EMS_DUP_STAGE   /* timing experiment: every elementary-step stage twice (idempotent) */
+        wave_lds_sync();
+        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, a, b, o, C.nm, C.nbOper, C.T1);
+#endif
         else es_stage(lists, lens, lane, a, b, o, C.nm, C.nbOper);
         wave_lds_sync();
     }
@@ -592,7 +614,7 @@ template <int LPE> __device__ __forceinline__ int row_excl_scan_i(int x, int rl)
 
 template <int Q, int LPE>
 __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
-                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big)
+                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big, float hint, float &T_out)
 {
     using G = Geo<Q, LPE>;
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
@@ -609,7 +631,8 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         float lo = rmin, hi = rmaxl;
         int clo = 1, chi = 0;
         bool hiv = false;
-        T = rmaxl;
+        const bool hinted = hint > rmin && hint < 3.0e38f;             // previous sweep's threshold of this edge
+        T = hinted ? hint : rmaxl;
         done = false;
         for (int it = 0; it < 12; ++it) {
             int c = 0;
@@ -624,7 +647,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                     if (c < nm) { lo = T; clo = c; } else { hi = T; chi = c; hiv = true; }
                     float nt;
                     if (!hiv) {
-                        nt = T + (T - rmin) + 1.0f;                        // gallop upward
+                        nt = (T < rmaxl) ? rmaxl : T + (T - rmin) + 1.0f;       // try the largest lane minimum, then gallop
                     } else {
                         float fr = (float)((nm + SEL_CAP) / 2 - clo) / (float)(chi - clo);
                         fr = fr < 0.125f ? 0.125f : (fr > 0.875f ? 0.875f : fr);
@@ -641,6 +664,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     }
     DBG_ADD(0, 1);
     if (__ballot(!done) != 0ull) { DBG_ADD(2, 1); return false; }
+    T_out = T;
 
     // ---- B ----
     int lc = 0;
@@ -737,10 +761,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     //      before the first use, so the visit pays one memory round trip. ----
     constexpr int NREC = (EMS_MAX_NM + LPE - 1) / LPE;
     float mvc[G::EPL];
+    float hint = __builtin_inff();
     load_row<Q, LPE>(app_row, rl, mvc);
     if (!first_sweep) {
-        const float dflt = *reinterpret_cast<const float *>(rec + 4 * nm);
-        const int cnt = rec[4 * nm + 4];
+        const float dflt = *reinterpret_cast<const float *>(rec + EMS_REC_DFLT(nm));
+        hint = *reinterpret_cast<const float *>(rec + EMS_REC_HINT(nm));
+        const int cnt = rec[EMS_REC_CNT(nm)];
         float rv[NREC];
         int rg[NREC];
 #pragma unroll
@@ -748,7 +774,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
             const int k = rl + c * LPE;
             const int kk = k < nm ? k : 0;
             rv[c] = reinterpret_cast<const float *>(rec)[kk];
-            rg[c] = rec[4 * nm + 5 + kk];
+            rg[c] = rec[EMS_REC_SYM(nm) + kk];
         }
         fill_row<Q, LPE>(drow, rl, dflt);
         wave_lds_sync();
@@ -767,11 +793,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     const int nmp = list_stride(nm);
     EmsEntry *inl = lists + t * nmp;
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
+    float T_sel = __builtin_inff();
 #ifdef EMS_ABLATE_SEL
     for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
     if (false)
 #endif
-    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
@@ -820,12 +847,13 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
         drow[g] = e.v;
         if (rowact) {
             reinterpret_cast<float *>(rec)[k] = e.v;
-            rec[4 * nm + 5 + k] = (uint8_t)g;
+            rec[EMS_REC_SYM(nm) + k] = (uint8_t)g;
         }
     }
     if (rowact && rl == 0) {
-        *reinterpret_cast<float *>(rec + 4 * nm) = dflt;
-        rec[4 * nm + 4] = (uint8_t)stp;
+        *reinterpret_cast<float *>(rec + EMS_REC_HINT(nm)) = T_sel;
+        *reinterpret_cast<float *>(rec + EMS_REC_DFLT(nm)) = dflt;
+        rec[EMS_REC_CNT(nm)] = (uint8_t)stp;
     }
     wave_lds_sync();
     float napp[G::EPL];
@@ -948,9 +976,11 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
             {
                 const int pp = (rl == 0 && row < C.dc) ? pred : -1;
                 unsigned spins = 0;
+                bool waited = false;
                 for (;;) {
                     const bool ok = pp < 0 || __hip_atomic_load(&done[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tag;
                     if (__ballot(!ok) == 0ull) break;
+                    waited = true;
                     if (++spins > (1u << 24)) {                // never expected; keeps a bug from hanging the GPU
                         if (lane == 0) atomicOr(spin_fail, 1u);
                         break;
@@ -958,6 +988,12 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsP
                     __builtin_amdgcn_s_sleep(2);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // A visit that had to wait for a predecessor sits on the frontier of the dependency chain;
+                // one whose inputs were ready long ago has slack.  Let the frontier win the SIMD arbitration.
+#ifndef EMS_NO_PRIO
+                if (waited) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(0);
+#endif
             }
             STAMP(4);
             process_cn<Q, LPE>(P, C, f, cn, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
@@ -1078,12 +1114,12 @@ __global__ void k_expand_ctov(const uint8_t *__restrict__ rec_base, int rec_byte
     const int e = blockIdx.x;
     if (e >= E) return;
     const uint8_t *rec = rec_base + (size_t)e * rec_bytes;
-    const float dflt = *reinterpret_cast<const float *>(rec + 4 * nm);
-    const int cnt = rec[4 * nm + 4];
+    const float dflt = *reinterpret_cast<const float *>(rec + EMS_REC_DFLT(nm));
+    const int cnt = rec[EMS_REC_CNT(nm)];
     for (int g = threadIdx.x; g < q; g += blockDim.x) out[(size_t)e * q + g] = dflt;
     __syncthreads();
     for (int k = threadIdx.x; k < cnt; k += blockDim.x)
-        out[(size_t)e * q + rec[4 * nm + 5 + k]] = reinterpret_cast<const float *>(rec)[k];
+        out[(size_t)e * q + rec[EMS_REC_SYM(nm) + k]] = reinterpret_cast<const float *>(rec)[k];
 }
 
 // ------------------------------------------------------------------------------------------------

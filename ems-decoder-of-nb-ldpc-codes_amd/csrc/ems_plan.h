@@ -22,9 +22,14 @@ struct EmsEntry {
 // q-wide float row per edge (init.c:323-328) although a C->V message is nm (LLR, symbol) pairs plus
 // one default value (bubble_decoder.c:262-278); the values are copies, never re-summed, so the compact
 // form is bit-exact.  Layout (bytes): [0,4nm) float vals[nm]; [4nm,4nm+4) float dflt;
-// [4nm+4] uint8 cnt; [4nm+5, 5nm+5) uint8 sym[nm] (symbol INDEX after the inverse rotation);
-// padded to a multiple of 16.
-static inline int ems_rec_bytes(int nm) { return ((5 * nm + 5) + 15) & ~15; }
+// [4nm+4,4nm+8) float hint (the selection threshold that worked for this edge in the previous sweep:
+// a search start only, never part of the result); [4nm+8] uint8 cnt; [4nm+9, 5nm+9) uint8 sym[nm]
+// (symbol INDEX after the inverse rotation); padded to a multiple of 16.
+static inline int ems_rec_bytes(int nm) { return ((5 * nm + 9) + 15) & ~15; }
+#define EMS_REC_DFLT(nm) (4 * (nm))
+#define EMS_REC_HINT(nm) (4 * (nm) + 4)
+#define EMS_REC_CNT(nm) (4 * (nm) + 8)
+#define EMS_REC_SYM(nm) (4 * (nm) + 9)
 
 struct EmsPlan {
     // code
