@@ -101,7 +101,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the decoder library has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("EMS_BENCH_FORCE_DIST"):      # the env knob rehearses the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
