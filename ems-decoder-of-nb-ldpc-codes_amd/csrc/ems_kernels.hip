@@ -94,7 +94,7 @@ template <int LPE> __device__ __forceinline__ void row_argmin(float &v, int &g)
 {
     argmin_step<DPP_XOR1>(v, g);
     argmin_step<DPP_XOR2>(v, g);
-    argmin_step<DPP_HMIRROR>(v, g);
+    if (LPE >= 8) argmin_step<DPP_HMIRROR>(v, g);
     if (LPE == 16) argmin_step<DPP_MIRROR>(v, g);
 }
 
@@ -589,7 +589,7 @@ template <int LPE, typename F> __device__ __forceinline__ float row_reduce_f(flo
     float o;
     o = dpp_f<DPP_XOR1>(x); x = better(o, x) ? o : x;
     o = dpp_f<DPP_XOR2>(x); x = better(o, x) ? o : x;
-    o = dpp_f<DPP_HMIRROR>(x); x = better(o, x) ? o : x;
+    if (LPE >= 8) { o = dpp_f<DPP_HMIRROR>(x); x = better(o, x) ? o : x; }
     if (LPE == 16) { o = dpp_f<DPP_MIRROR>(x); x = better(o, x) ? o : x; }
     return x;
 }
@@ -597,7 +597,7 @@ template <int LPE> __device__ __forceinline__ int row_sum_i(int x)
 {
     x += dpp_i<DPP_XOR1>(x);
     x += dpp_i<DPP_XOR2>(x);
-    x += dpp_i<DPP_HMIRROR>(x);
+    if (LPE >= 8) x += dpp_i<DPP_HMIRROR>(x);
     if (LPE == 16) x += dpp_i<DPP_MIRROR>(x);
     return x;
 }
@@ -607,7 +607,7 @@ template <int LPE> __device__ __forceinline__ int row_excl_scan_i(int x, int rl)
     int inc = x, t;
     t = dpp_i<0x111>(inc); inc += (rl >= 1) ? t : 0;
     t = dpp_i<0x112>(inc); inc += (rl >= 2) ? t : 0;
-    t = dpp_i<0x114>(inc); inc += (rl >= 4) ? t : 0;
+    if (LPE >= 8) { t = dpp_i<0x114>(inc); inc += (rl >= 4) ? t : 0; }
     if (LPE == 16) { t = dpp_i<0x118>(inc); inc += (rl >= 8) ? t : 0; }
     return inc - x;
 }
@@ -898,7 +898,7 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE, int DC, int NM>
-__global__ void __launch_bounds__((LPE == 8 ? 16 : 12) * 64) k_decode(const EmsPlan P)
+__global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
     Cfg C;
@@ -1237,10 +1237,10 @@ template <typename T> hipError_t set_max_lds(T kernel, size_t bytes)
 // ================================================================================================
 // host-side launchers
 // ================================================================================================
-int ems_lpe_for(int dc) { return dc <= 4 ? 16 : (dc <= 8 ? 8 : 0); }
+int ems_lpe_for(int dc) { return dc <= 4 ? 16 : (dc <= 8 ? 8 : (dc <= 16 ? 4 : 0)); }   // dc 9..16: GF(16)/GF(64) only
 // waves per workgroup the decode kernel is compiled for: the dc <= 4 kernels keep q/16 values per lane in
 // registers and need the 170-VGPR budget of 12 waves; the dc <= 8 kernels fit the 128 of 16 waves
-int ems_max_waves_for(int dc) { return ems_lpe_for(dc) == 8 ? 16 : 12; }
+int ems_max_waves_for(int dc) { const int l = ems_lpe_for(dc); return l == 8 ? 16 : (l == 4 ? 8 : 12); }
 
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {
@@ -1279,6 +1279,9 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
         if (P.q == 256) return launch_decode_t<256, 8>(P, B, st);
         if (P.q == 64) return launch_decode_t<64, 8>(P, B, st);
         if (P.q == 16) return launch_decode_t<16, 8>(P, B, st);
+    } else if (lpe == 4) {
+        if (P.q == 64) return launch_decode_t<64, 4>(P, B, st);
+        if (P.q == 16) return launch_decode_t<16, 4>(P, B, st);
     }
     return hipErrorInvalidValue;
 }

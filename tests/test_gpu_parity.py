@@ -132,6 +132,28 @@ def test_decode_n96_other_parameters(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Mat24_N192_M96", 24, 48, 1.0, 20, 1.75, 24)        # NB_LDPC.c:55-57
 
 
+def test_decode_generic_kernels_other_degrees(pkg, orc):
+    """Codes outside the specialised (dc, nm) instantiations: dc = 6, 8 and 12 over GF(64) (rows of 8 and 4
+    lanes), GF(256) with dc = 4 at a non-default nm, GF(256) with dc = 8."""
+    _decode_vs_oracle(pkg, orc, "Mat26_N48_M16", 12, 24, 0.5, 12, 3.5, 24)            # dc = 6
+    _decode_vs_oracle(pkg, orc, "Mat28_N72_M18", 16, 32, 0.3, 10, 4.0, 16)            # dc = 8
+    _decode_vs_oracle(pkg, orc, "Mat212_N96_M16", 12, 24, 0.3, 8, 5.0, 12)            # dc = 12
+    _decode_vs_oracle(pkg, orc, "KN_N576_K480_GF64.txt", 30, 45, 0.3, 10, 4.0, 6)     # start.sh:8-13 parameters
+    _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 24, 40, 0.3, 15, 2.5, 32)    # GF(256), dc = 4, nm = 24
+    _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 20, 22, 0.3, 15, 2.5, 8)     # NbOper < nm + 3: generic kernel
+
+
+def test_decode_gf256_dc8_vs_oracle(pkg, orc):
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF256", 20, 40, 0.3, 12, 3.2, 1, state=True)
+
+
+def test_unsupported_configurations_fail_loudly(pkg):
+    code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
+    with pytest.raises(pkg.EmsError) as e:
+        pkg.Decoder(code, 40, 60, 0.3, 10, max_batch=1)          # nm > 32
+    assert e.value.code == pkg.EMS_EINVAL
+
+
 def test_decode_gf16_vs_oracle(pkg, orc):
     it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 4)
     assert list(it) == [6, 5, 5, 5]                    # K3
