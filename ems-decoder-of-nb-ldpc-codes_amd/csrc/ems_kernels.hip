@@ -215,6 +215,7 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
 // ------------------------------------------------------------------------------------------------
 // (bit pattern of 1e5f is 0x47C35000)
 constexpr int ES_MAX_STEPS = 64;
+constexpr int ES_PICK_BYTES = 8 * (ES_MAX_STEPS + 4) + 64 * 4;   // 8 pick areas + one dummy dword per lane
 
 __device__ __forceinline__ unsigned red8_minu(unsigned x)
 {
@@ -373,8 +374,8 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     const EmsEntry *in2 = lists + (has ? b_id : 0) * nmp;
     EmsEntry *out = lists + (has ? o_id : 0) * nmp;
     unsigned *tbl = tbl_base + gsel * q;
-    uint8_t *picks = picks_base + (lane >> 3) * ES_MAX_STEPS;    // 8 areas: lanes without a task scribble in theirs
-    uint8_t *dummy = picks_base + 8 * ES_MAX_STEPS + lane;
+    uint8_t *picks = picks_base + (lane >> 3) * (ES_MAX_STEPS + 4); // 8 areas 17 dwords apart (bank spread); lanes without a task scribble in theirs
+    uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;  // one dword per lane: no same-dword byte writes
 
     if (has) {
 #pragma unroll 5
@@ -577,6 +578,9 @@ __device__ __forceinline__ void select_rounds(const float (&mvc)[Geo<Q, LPE>::EP
 // channel): the caller then runs the literal select_rounds path.
 // ------------------------------------------------------------------------------------------------
 constexpr int SEL_CAP = 32;
+// survivor entries per edge row: SEL_CAP survivors + one dummy slot per lane + a pad that spreads the rows
+// over the LDS banks (row bases 8/20/10 dwords apart modulo 32 for 4/8/16 rows)
+__host__ __device__ constexpr int surv_stride(int lpe) { return SEL_CAP + lpe + (lpe == 16 ? 4 : (lpe == 8 ? 2 : 1)); }
 
 __device__ __forceinline__ unsigned mono_key(float v)
 {
@@ -798,7 +802,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
     if (false)
 #endif
-    if (!select_threshold<Q, LPE>(mvc, surv + row * (SEL_CAP + LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
@@ -927,7 +931,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64) k_
 
     uint8_t *wbase = smem + wg_header_bytes(Q, P.M) + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
-    constexpr int SURV_BYTES = G::NROWS * (SEL_CAP + LPE) * 8;       // survivor scratch of the selection
+    constexpr int SURV_BYTES = G::NROWS * surv_stride(LPE) * 8;      // survivor scratch of the selection
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
     int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
@@ -1132,7 +1136,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     __shared__ EmsEntry lists[3 * (EMS_MAX_NM + 2)];
     __shared__ int lens[4];
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
-    __shared__ uint8_t picks[9 * 64];
+    __shared__ uint8_t picks[ES_PICK_BYTES];
     const int lane = threadIdx.x;
     const int nmp = list_stride(nm);
     bool big = false;
@@ -1166,7 +1170,7 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(smem);
     int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * nmp * 8 + 15) & ~15));
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
-    __shared__ uint8_t picks[9 * 64];
+    __shared__ uint8_t picks[ES_PICK_BYTES];
     const int lane = threadIdx.x;
     bool big = false;
     for (int i = lane; i < dc * nmp; i += 64) {                // rotation, bubble_decoder.c:133-152
@@ -1246,10 +1250,10 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {
     const int lpe = ems_lpe_for(dc);
     if (!lpe) return 0;
-    const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * (32 + lpe) * 8; // staging rows + survivor scratch
+    const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * surv_stride(lpe) * 8; // staging rows + survivor scratch
     const size_t lists = ((size_t)n_lists * list_stride(nm) * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens + 9 * 64; // + pick bytes of the elementary steps
+    return dense + lists + lens + ES_PICK_BYTES; // + pick bytes of the elementary steps
 }
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
