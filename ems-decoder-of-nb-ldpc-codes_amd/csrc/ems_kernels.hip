@@ -588,6 +588,19 @@ __device__ __forceinline__ unsigned mono_key(float v)
     return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
 }
 
+// IEEE min/max of two non-NaN floats in one instruction (fminf/fmaxf would add canonicalising v_max's; a
+// compare + select costs three issue slots with the VCC hazard).  Not volatile: the compiler may schedule it.
+__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int LPE, bool MAX> __device__ __forceinline__ float row_minmax_f(float x)
+{
+    x = MAX ? vmaxf(x, dpp_f<DPP_XOR1>(x)) : vminf(x, dpp_f<DPP_XOR1>(x));
+    x = MAX ? vmaxf(x, dpp_f<DPP_XOR2>(x)) : vminf(x, dpp_f<DPP_XOR2>(x));
+    if (LPE >= 8) x = MAX ? vmaxf(x, dpp_f<DPP_HMIRROR>(x)) : vminf(x, dpp_f<DPP_HMIRROR>(x));
+    if (LPE == 16) x = MAX ? vmaxf(x, dpp_f<DPP_MIRROR>(x)) : vminf(x, dpp_f<DPP_MIRROR>(x));
+    return x;
+}
+
 template <int LPE, typename F> __device__ __forceinline__ float row_reduce_f(float x, F better)
 {
     float o;
@@ -653,7 +666,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                     if (!hiv) {
                         nt = (T < rmaxl) ? rmaxl : T + (T - rmin) + 1.0f;       // try the largest lane minimum, then gallop
                     } else {
-                        float fr = (float)((nm + SEL_CAP) / 2 - clo) / (float)(chi - clo);
+                        float fr = (float)((nm + SEL_CAP) / 2 - clo) * __builtin_amdgcn_rcpf((float)(chi - clo));   // steering only
                         fr = fr < 0.125f ? 0.125f : (fr > 0.875f ? 0.875f : fr);
                         nt = lo + (hi - lo) * fr;
                         if (!(nt > lo && nt < hi)) nt = lo + (hi - lo) * 0.5f;
@@ -902,7 +915,8 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE, int DC, int NM>
-__global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64) k_decode(const EmsPlan P)
+// (the small GF(64)/dc=4 specialisation runs many 2-wave workgroups per CU: ask for 4 waves per SIMD there)
+__global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q == 64 && DC == 4) ? 4 : 1) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
     Cfg C;
