@@ -1061,26 +1061,39 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
 }
 
 // ------------------------------------------------------------------------------------------------
-// Channel LLR (channel.c:66-76): one thread per (frame, variable node, symbol).  The float/double
-// promotion order of the reference expression is kept term by term.
+// Channel LLR (channel.c:66-76).  A block of 256 threads handles 256/q variable nodes, one thread per
+// (variable node, symbol).  The reference evaluates, per symbol and bit,
+//     TMP = TMP + SQR(y - BPSK(bit)) / (2.0 * SQR(sigma))        (float, float ops, double divide + add)
+// The double quotient depends only on (variable node, bit position, bit value): the 2*logq quotients of a
+// node are computed once (same operands, same IEEE divide => same bits) and every symbol then accumulates
+// them in the reference's order, rounding the running sum to float after every bit as the reference does.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_llr_init(const float *__restrict__ noisy, float sigma, int logq, int q, size_t total,
-                           const uint8_t *__restrict__ idx2bin, float *__restrict__ app)
+__global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ noisy, float sigma, int logq, int q, size_t nvn,
+                                                  const uint8_t *__restrict__ idx2bin, float *__restrict__ app)
 {
+    __shared__ double quo[16][8][2];                           // [node in block][bit][bit value]
+    const int per = 256 / q;                                   // variable nodes per block (q <= 256)
     const double denom = 2.0 * (double)(sigma * sigma);        // 2.0*SQR(sigma), SQR in float
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t fn = i / q;
-        const int g = (int)(i - fn * q);
-        const unsigned img = idx2bin[g];
-        const float *y = noisy + fn * logq;
-        float t = 0.0f;
-        for (int l = 0; l < logq; ++l) {
-            const float s = ((img >> l) & 1u) ? -1.0f : 1.0f;  // BPSK(x) = 1-2x (channel.h:14)
-            const float a = y[l] - s;
-            const float sq = a * a;
-            t = (float)((double)t + (double)sq / denom);
+    const int tid = threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * per; base < nvn; base += (size_t)gridDim.x * per) {
+        if (tid < per * logq * 2) {
+            const int v = tid / (logq * 2), r = tid - v * (logq * 2), l = r >> 1, b = r & 1;
+            if (base + v < nvn) {
+                const float s = b ? -1.0f : 1.0f;              // BPSK(x) = 1-2x (channel.h:14)
+                const float a = noisy[(base + v) * logq + l] - s;
+                const float sq = a * a;
+                quo[v][l][b] = (double)sq / denom;
+            }
         }
-        app[i] = t;
+        __syncthreads();
+        const int v = tid / q, g = tid - v * q;
+        if (v < per && base + v < nvn) {
+            const unsigned img = idx2bin[g];
+            float t = 0.0f;
+            for (int l = 0; l < logq; ++l) t = (float)((double)t + quo[v][l][(img >> l) & 1u]);
+            app[(base + v) * q + g] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1307,11 +1320,11 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
                                const uint8_t *idx2bin_dev, float *app_dev, hipStream_t st)
 {
-    const int threads = 256;
-    size_t blocks = (total + threads - 1) / threads;
-    if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(threads), 0, st, noisy_dev, sigma, logq, q, total,
-                       idx2bin_dev, app_dev);
+    const size_t nvn = total / q;                              // (frame, variable node) pairs
+    const int per = 256 / q;
+    size_t blocks = (nvn + per - 1) / per;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(256), 0, st, noisy_dev, sigma, logq, q, nvn, idx2bin_dev, app_dev);
     return hipGetLastError();
 }
 
