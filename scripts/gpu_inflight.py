@@ -17,7 +17,9 @@ for i in range(ninf):
     decs.append(d)
 for rep in range(3):
     t0 = time.perf_counter()
-    for d in decs: d.decode(B)
+    for d in decs:
+        if os.environ.get('WITH_LLR'): d.llr_init_dev(d.noisy_dev_ptr, sigma, B)
+        d.decode(B)
     for d in decs: d.synchronize()
     dt = time.perf_counter() - t0
     print("inflight=%d waves=%s: %.1f ms wall -> %.1f frames/s (kernel ms %s)" % (ninf, os.environ.get("EMS_WAVES", "default"), dt * 1e3, ninf * B / dt,
