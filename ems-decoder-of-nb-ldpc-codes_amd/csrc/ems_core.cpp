@@ -180,10 +180,10 @@ struct ems_handle {
     int device = 0, max_batch = 0, nm_alloc = 0;
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
-    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred;
+    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp;
     std::vector<uint8_t> cn_lh, i2b, b2i;
     CnSchedule cs;
-    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred;
+    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
@@ -209,7 +209,7 @@ int refresh_plan(ems_handle *h)
     P.n_levels = (int)h->lvl_ptr.size() - 1;
     P.lvl_ptr = h->d_lvl_ptr.p; P.lvl_cn = h->d_lvl_cn.p; P.cn_vn = h->d_cn_vn.p; P.cn_lh = h->d_cn_lh.p;
     P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
-    P.t_cn = h->d_lvl_cn.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
+    P.t_cn = h->d_t_cnp.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
@@ -339,7 +339,7 @@ void ems_destroy(ems_handle *h)
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
-    h->d_scratch.release(); h->d_stamps.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release();
+    h->d_scratch.release(); h->d_stamps.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -402,6 +402,31 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
                 h->t_pred[(size_t)i * h->dc + k] = pred_cn[e] < 0 ? -1 : task_of[pred_cn[e]];
             }
         }
+        // Static SIMD-arbitration priority of each visit from its slack in the sweep's dependency DAG:
+        // slack = (longest chain) - (longest chain through this task).  Tasks on (or near) a longest chain
+        // gate the sweep; tasks with a lot of slack can yield issue slots to them.  Packed into bits 24..25
+        // of the task's check-node word.
+        {
+            std::vector<int> depth(h->M, 0), height(h->M, 0);
+            for (int i = 0; i < h->M; ++i)
+                for (int k = 0; k < h->dc; ++k) {
+                    const int pr = h->t_pred[(size_t)i * h->dc + k];
+                    if (pr >= 0) depth[i] = std::max(depth[i], depth[pr] + 1);
+                }
+            for (int i = h->M - 1; i >= 0; --i)
+                for (int k = 0; k < h->dc; ++k) {
+                    const int pr = h->t_pred[(size_t)i * h->dc + k];
+                    if (pr >= 0) height[pr] = std::max(height[pr], height[i] + 1);
+                }
+            int cp = 0;
+            for (int i = 0; i < h->M; ++i) cp = std::max(cp, depth[i] + height[i]);
+            h->t_cnp.resize(h->M);
+            for (int i = 0; i < h->M; ++i) {
+                const int slack = cp - (depth[i] + height[i]);
+                const int prio = slack <= 2 ? 3 : (slack <= 8 ? 2 : (slack <= 24 ? 1 : 0));
+                h->t_cnp[i] = h->lvl_cn[i] | (prio << 24);
+            }
+        }
     }
 
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
@@ -410,7 +435,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     const size_t B = (size_t)max_batch;
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
-        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))

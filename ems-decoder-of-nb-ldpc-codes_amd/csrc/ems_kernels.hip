@@ -975,7 +975,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
         int cur = claim();
         int cn = 0, vn = 0, lh = 0, pred = -1;
         if (cur < P.M) {
-            cn = P.t_cn[cur];
+            cn = P.t_cn[cur];                                  // check node | priority << 24
             vn = P.t_vn[cur * C.dc + trow];
             lh = P.t_lh[cur * C.dc + trow];
             pred = P.t_pred[cur * C.dc + trow];
@@ -1009,12 +1009,17 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
                 // A visit that had to wait for a predecessor sits on the frontier of the dependency chain;
                 // one whose inputs were ready long ago has slack.  Let the frontier win the SIMD arbitration.
 #ifndef EMS_NO_PRIO
-                if (waited) __builtin_amdgcn_s_setprio(3);
-                else __builtin_amdgcn_s_setprio(0);
+                (void)waited;
+                switch (cn >> 24) {                            // static priority from the task's slack (host)
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+                }
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif

@@ -44,7 +44,7 @@ struct EmsPlan {
     const int *cn_vn;       // [M*dc] variable node of edge (cn*dc+i)      (code_t.mat)
     const uint8_t *cn_lh;   // [M*dc] log_alpha of the edge coefficient = index-1 (code_t.matValue)
     // the same check nodes as a task list in dependency (level) order, for the dataflow scheduler
-    const int *t_cn;        // [M]    check node of task i
+    const int *t_cn;        // [M]    check node of task i (bits 0..23) | SIMD priority 0..3 (bits 24..25)
     const int *t_vn;        // [M*dc] its variable nodes
     const int *t_lh;        // [M*dc] log of its coefficients
     const int *t_pred;      // [M*dc] task index of the previous visitor of that variable node in this sweep, or -1
