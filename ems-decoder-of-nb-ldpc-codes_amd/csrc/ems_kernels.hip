@@ -230,9 +230,8 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
                                         const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
                                         int nbOper, int &S_out)
 {
+    // tbl is all-zero on entry (and left all-zero: every claimed entry is cleared again below)
     wave_lds_sync();
-    if (has)
-        for (int w = p * 4; w < q; w += 32) *reinterpret_cast<uint4 *>(tbl + w) = uint4{0u, 0u, 0u, 0u};
     float val[NJ];
     unsigned sym[NJ];
     int lim = 1 << 20;
@@ -270,6 +269,10 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
         if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
         base += __popc(m8);
     }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (has && p + 8 * j < lim) tbl[sym[j]] = 0u;
     S_out = min(base, nm);
     return (base >= nm) || stopped || (T >= nbOper);
 }
@@ -292,8 +295,6 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
         sy = sym_comb(e1.s, e2.s);
     };
     wave_lds_sync();
-    if (has)
-        for (int w = p * 4; w < q; w += 32) *reinterpret_cast<uint4 *>(tbl + w) = uint4{0u, 0u, 0u, 0u};
     int lim = 1 << 20;
     for (int j = 0; j < NJ; ++j) {
         const int i = p + 8 * j;
@@ -324,6 +325,13 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{v, sy & 0xFFu};
         base += __popc(m8);
+    }
+    wave_lds_sync();
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        float v; unsigned sy; int k;
+        gather(i, has && i < T, v, sy, k);
+        if (has && i < lim) tbl[sy & 0xFFu] = 0u;
     }
     S_out = min(base, nm);
     return (base >= nm) || stopped || (T >= nbOper);
@@ -428,7 +436,8 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 #ifdef EMS_DUP_POST   /* timing experiment: the post-pass twice (idempotent) */
     if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
 #endif
-    if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    if (T1 <= 16) done = es_post<2>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    else if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
         // rare: neither nm outputs nor a stop within the first nm+3 picks -> merge on up to nbOper
@@ -755,7 +764,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                           EmsEntry *lists, int *lens, uint8_t *picks, int lane
+                                           EmsEntry *lists, int *lens, uint8_t *picks, unsigned *tbl, int lane
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -843,7 +852,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
 #ifndef EMS_ABLATE_ES
-    cn_core(C, lists, lens, reinterpret_cast<unsigned *>(dense), picks, lane, __ballot(big) != 0ull);
+    cn_core(C, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
 #else
     if (lane < 16) lens[lane < C.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
     wave_lds_sync();
@@ -949,13 +958,15 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
     int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
-    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((C.n_lists * 4 + 15) & ~15);   // 8 x 64 pick bytes + 64 dummies
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((C.n_lists * 4 + 15) & ~15);   // 8 x 68 pick bytes + 64 dummy dwords
+    unsigned *tbl = reinterpret_cast<unsigned *>(picks + ((ES_PICK_BYTES + 15) & ~15));   // 4 dedupe tables of Q words, kept all-zero between uses
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
         t_b2i[i] = P.bin2idx[i];
     }
     for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
+    for (int i = lane; i < 4 * Q; i += 64) tbl[i] = 0u;
     if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
 
@@ -1019,7 +1030,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, tbl, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
@@ -1172,6 +1183,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     const int lane = threadIdx.x;
     const int nmp = list_stride(nm);
     bool big = false;
+    for (int i = lane; i < 4 * 256; i += 64) tbl[i] = 0u;
     for (int k = lane; k < nmp; k += 64) {
         const bool pad = k >= nm;
         const float v1 = pad ? __builtin_inff() : in1[k], v2 = pad ? __builtin_inff() : in2[k];
@@ -1205,6 +1217,7 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     __shared__ uint8_t picks[ES_PICK_BYTES];
     const int lane = threadIdx.x;
     bool big = false;
+    for (int i = lane; i < 4 * 256; i += 64) tbl[i] = 0u;
     for (int i = lane; i < dc * nmp; i += 64) {                // rotation, bubble_decoder.c:133-152
         const int t = i / nmp, k = i - t * nmp;
         if (k >= nm) {
@@ -1285,7 +1298,7 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
     const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * surv_stride(lpe) * 8; // staging rows + survivor scratch
     const size_t lists = ((size_t)n_lists * list_stride(nm) * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens + ES_PICK_BYTES; // + pick bytes of the elementary steps
+    return dense + lists + lens + ((ES_PICK_BYTES + 15) & ~15) + (size_t)4 * q * 4; // + pick bytes and dedupe tables of the elementary steps
 }
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
