@@ -215,7 +215,7 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
 // ------------------------------------------------------------------------------------------------
 // (bit pattern of 1e5f is 0x47C35000)
 constexpr int ES_MAX_STEPS = 64;
-constexpr int ES_PICK_BYTES = 8 * (ES_MAX_STEPS + 4) + 64 * 4;   // 8 pick areas + one dummy dword per lane
+constexpr int ES_PICK_BYTES = 8 * (ES_MAX_STEPS + 4) + 64 * 4 + ES_MAX_STEPS;   // 8 pick areas + one dummy dword per lane (+ step offset)
 
 __device__ __forceinline__ unsigned red8_minu(unsigned x)
 {
@@ -240,7 +240,7 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
         const int i = p + 8 * j;
         const bool ok = has && i < T;
         const unsigned pk = picks[ok ? i : 0];
-        const int w = pk & 7, k = pk >> 3;
+        const int w = pk >> 5, k = pk & 31;
         const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
         const EmsEntry e1 = in1[r], e2 = in2[c];
         val[j] = e1.v + e2.v;
@@ -287,8 +287,8 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     const int NJ = (T + 7) >> 3;
     auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &k) {
         const unsigned pk = picks[ok ? i : 0];
-        const int w = pk & 7;
-        k = pk >> 3;
+        const int w = pk >> 5;
+        k = pk & 31;
         const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
         const EmsEntry e1 = in1[r], e2 = in2[c];
         v = e1.v + e2.v;
@@ -355,19 +355,39 @@ __device__ __forceinline__ int red8_sumi(int x)
 // Both rely on the caller's guard: every valid value in the visit is in [0, 1e4), hence (a) float order ==
 // unsigned order of the bit patterns and (b) a head >= 1e5 always involves an invalid (padded) entry, so
 // whichever such head is taken the step is the "source index -1 -> break" stop of bubble_decoder.c:478.
+// A pick is recorded as one byte, competitor p in bits 5..7 and its list position in bits 0..4; the loop
+// carries y = 32 p + pos so that the byte is y itself and the list address is one shift-add away.
 template <bool EXACT>
-__device__ __forceinline__ void es_merge(unsigned &hv, int &pos, float &nxv, float fxv, const EmsEntry *mv, uint8_t *pk,
+__device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const EmsEntry *mvy, uint8_t *pk,
                                          uint8_t *dummy, int p, int gbase, int from, int to)
 {
-    for (int ss = from; ss < to; ++ss) {
+    // The next-head operand mv[pos+1] is fetched two steps ahead so that the LDS latency (~110 cycles, more
+    // than one step) stays off the loop-carried path: each step issues the pair (mv[pos+1], mv[pos+2]) for
+    // its updated position; the step after next picks the element of that pair its predecessor's outcome
+    // (advance or not) makes current.  Two pairs alternate, each reloaded by the step that consumed it.
+    // mvy = mv - 32 p entries, i.e. mvy[y] == mv[pos].
+    float a0 = mvy[y + 1].v, a1 = mvy[y + 2].v;
+    float b0 = a0, b1 = a1;
+    bool wprev = false;
+    auto step = [&](float &x0, float &x1, int ss) {
         const unsigned m = red8_minu(hv);
         bool iw = (hv == m);
         if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
-        *(iw ? pk + ss : dummy) = (uint8_t)(p | (pos << 3));
-        pos += iw ? 1 : 0;
-        hv = iw ? (unsigned)__float_as_int(fxv + nxv) : hv;
-        nxv = mv[pos + 1].v;
+        const float nx = wprev ? x1 : x0;
+        (iw ? pk : dummy)[ss] = (uint8_t)y;      // losers write to their own dummy dword (+ss: still one dword per lane)
+        y += iw ? 1 : 0;
+        hv = iw ? (unsigned)__float_as_int(fxv + nx) : hv;
+        x0 = mvy[y + 1].v;
+        x1 = mvy[y + 2].v;
+        wprev = iw;
+    };
+    int ss = from;
+#pragma unroll
+    for (; ss + 1 < to; ss += 2) {
+        step(a0, a1, ss);
+        step(b0, b1, ss + 1);
     }
+    if (ss < to) step(a0, a1, ss);
 }
 
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
@@ -392,46 +412,23 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 
     const bool rowc = p < 4;
     const EmsEntry *mv = rowc ? in2 : in1;
-    const int pos0 = rowc ? 0 : 4;
+    const EmsEntry *mvy = mv - 32 * p;
+    const int pos0 = (rowc ? 0 : 4) + 32 * p;
     const float fxv = rowc ? in1[p].v : in2[p - 4].v;
     unsigned hv;
     int pos;
-    float nxv;
     auto init = [&]() {
         pos = pos0;
-        hv = (unsigned)__float_as_int(fxv + mv[pos0].v);         // tab_aux[r][c] = In1[r] + In2[c]
-        nxv = mv[pos0 + 1].v;
+        hv = (unsigned)__float_as_int(fxv + mvy[pos0].v);        // tab_aux[r][c] = In1[r] + In2[c]
     };
 
     int S = 0;
     bool done;
     init();
-    es_merge<false>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
-#ifdef EMS_DUP_LOOP   /* timing experiment: the merge loop twice (the 2nd run's picks are discarded) */
-    {
-        const unsigned hv_s = hv; const int pos_s = pos; const float nxv_s = nxv;
-        init();
-        for (int ss = 0; ss < T1; ++ss) {
-            const unsigned m = red8_minu(hv);
-            const bool iw = (hv == m);
-#if EMS_DUP_LOOP != 2
-            *(iw ? dummy : dummy) = (uint8_t)(p | (pos << 3));
-#endif
-            pos += iw ? 1 : 0;
-            hv = iw ? (unsigned)__float_as_int(fxv + nxv) : hv;
-#if EMS_DUP_LOOP != 3
-            nxv = mv[pos + 1].v;
-#else
-            nxv = nxv + 1.0f;
-#endif
-        }
-        asm volatile("" :: "v"(hv), "v"(pos), "v"(nxv));
-        hv = hv_s; pos = pos_s; nxv = nxv_s;
-    }
-#endif
+    es_merge<false>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
         init();
-        es_merge<true>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, 0, T1);
+        es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
 #ifdef EMS_DUP_POST   /* timing experiment: the post-pass twice (idempotent) */
     if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
@@ -441,7 +438,7 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
         // rare: neither nm outputs nor a stop within the first nm+3 picks -> merge on up to nbOper
-        es_merge<true>(hv, pos, nxv, fxv, mv, picks, dummy, p, gbase, T1, nbOper);
+        es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, T1, nbOper);
         es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
     }
     if (has && p == 0) lens[o_id] = S;
