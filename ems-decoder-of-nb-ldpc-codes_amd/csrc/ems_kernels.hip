@@ -391,16 +391,18 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
 }
 
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
-                                              int lane, int a_id, int b_id, int o_id, int nm, int nbOper, int T1)
+                                              int lane, uint2 task, int nm, int nbOper, int T1)
 {
     const int p = lane & 7;
     const int gbase = lane & ~7;
     const int gsel = (lane >> 3) & 3;
-    const bool has = o_id >= 0;
+    const bool has = (task.y >> 16) != 0u;          // see es_task(): byte offsets of the lists, output id + 1
+    const int o_id = (int)(task.y >> 16) - 1;
     const int nmp = list_stride(nm);
-    const EmsEntry *in1 = lists + (has ? a_id : 0) * nmp;
-    const EmsEntry *in2 = lists + (has ? b_id : 0) * nmp;
-    EmsEntry *out = lists + (has ? o_id : 0) * nmp;
+    uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
+    const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (task.x & 0xFFFFu));
+    const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (task.x >> 16));
+    EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (task.y & 0xFFFFu));
     unsigned *tbl = tbl_base + gsel * q;
     uint8_t *picks = picks_base + (lane >> 3) * (ES_MAX_STEPS + 4); // 8 areas 17 dwords apart (bank spread); lanes without a task scribble in theirs
     uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;  // one dword per lane: no same-dword byte writes
@@ -457,33 +459,59 @@ __device__ __forceinline__ int list_P(int dc, int k) { return k == 0 ? 0 : dc + 
 __device__ __forceinline__ int list_S(int dc, int k) { return k == dc - 1 ? dc - 1 : dc + (dc - 2) + (k - 1); }
 __device__ __forceinline__ int list_M(int dc, int k) { return dc + 2 * (dc - 2) + k; }
 
-__device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, int lane,
-                                        bool literal)
+// One elementary-step task of a stage as the 8-lane groups read it from LDS: x = byte offset of In1 | byte
+// offset of In2 << 16 (relative to the wave's list area), y = byte offset of Out | (list id of Out + 1) << 16;
+// all-zero = no task for this group.
+__device__ __forceinline__ uint2 es_task(int a, int b, int o, int nmp)
+{
+    if (o < 0) return uint2{0u, 0u};
+    return uint2{(unsigned)(a * nmp * 8) | ((unsigned)(b * nmp * 8) << 16), (unsigned)(o * nmp * 8) | ((unsigned)(o + 1) << 16)};
+}
+constexpr int CN_SCHED_BYTES = EMS_MAX_STEPS * 8 * 8;   // [stage][group] tasks of one check-node visit
+
+// Task (stage t = 1..dc-2, group grp) of the forward/backward/merge schedule of bubble_decoder.c:166-227.
+__device__ __forceinline__ uint2 cn_task(int dc, int nmp, int t, int grp)
+{
+    // step t: forward P(t) = ES(P(t-1), in(t)); backward S(dc-1-t) = ES(S(dc-t), in(dc-1-t)); and the
+    // merges M(k) = ES(P(k), S(k+2)) that became ready after step t-1, lowest k first
+    const int k1 = t - 1, k2 = dc - 2 - t;
+    const bool v1 = k1 <= dc - 3 && 2 * k1 >= dc - 3;
+    const bool v2 = k2 >= 0 && k2 <= t - 1 && k2 != k1;
+    int ka = -1, kb = -1;
+    if (v1 && v2) { ka = min(k1, k2); kb = max(k1, k2); }
+    else if (v1) ka = k1;
+    else if (v2) ka = k2;
+    int a = -1, b = -1, o = -1;
+    if (grp == 0) { a = list_P(dc, t - 1); b = t; o = list_P(dc, t); }
+    else if (grp == 1) { a = list_S(dc, dc - t); b = dc - 1 - t; o = list_S(dc, dc - 1 - t); }
+    else if (grp == 2 && ka >= 0) { a = list_P(dc, ka); b = list_S(dc, ka + 2); o = list_M(dc, ka); }
+    else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
+    return es_task(a, b, o, nmp);
+}
+// filled once per kernel by the whole workgroup (caller synchronises)
+__device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int tid, int nthreads)
+{
+    for (int i = tid; i < (dc - 2) * 8; i += nthreads) sched[i] = cn_task(dc, list_stride(nm), (i >> 3) + 1, i & 7);
+}
+
+__device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
+                                        int lane, bool literal)
 {
     const int grp = lane >> 3;
-    const int dc = C.dc;
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= C.nsteps; ++t) {
-        // step t: forward P(t) = ES(P(t-1), in(t)); backward S(dc-1-t) = ES(S(dc-t), in(dc-1-t)); and the
-        // merges M(k) = ES(P(k), S(k+2)) that became ready after step t-1, lowest k first
-        const int k1 = t - 1, k2 = dc - 2 - t;
-        const bool v1 = k1 <= dc - 3 && 2 * k1 >= dc - 3;
-        const bool v2 = k2 >= 0 && k2 <= t - 1 && k2 != k1;
-        int ka = -1, kb = -1;
-        if (v1 && v2) { ka = min(k1, k2); kb = max(k1, k2); }
-        else if (v1) ka = k1;
-        else if (v2) ka = k2;
-        int a = -1, b = -1, o = -1;
-        if (grp == 0) { a = list_P(dc, t - 1); b = t; o = list_P(dc, t); }
-        else if (grp == 1) { a = list_S(dc, dc - t); b = dc - 1 - t; o = list_S(dc, dc - 1 - t); }
-        else if (grp == 2 && ka >= 0) { a = list_P(dc, ka); b = list_S(dc, ka + 2); o = list_M(dc, ka); }
-        else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
-        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, a, b, o, C.nm, C.nbOper, C.T1);
+        const uint2 task = sched[(t - 1) * 8 + grp];
+        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
 #ifdef EMS_DUP_STAGE   /* timing experiment: every elementary-step stage twice (idempotent) */
         wave_lds_sync();
-        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, a, b, o, C.nm, C.nbOper, C.T1);
+        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
 #endif
-        else es_stage(lists, lens, lane, a, b, o, C.nm, C.nbOper);
+        else {
+            const int lb = list_stride(C.nm) * 8;
+            const bool has = (task.y >> 16) != 0u;
+            es_stage(lists, lens, lane, has ? (int)(task.x & 0xFFFFu) / lb : -1, has ? (int)(task.x >> 16) / lb : -1,
+                     has ? (int)(task.y >> 16) - 1 : -1, C.nm, C.nbOper);
+        }
         wave_lds_sync();
     }
 }
@@ -761,7 +789,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                           EmsEntry *lists, int *lens, uint8_t *picks, unsigned *tbl, int lane
+                                           EmsEntry *lists, int *lens, uint8_t *picks, unsigned *tbl, const uint2 *sched, int lane
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -849,7 +877,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
 #ifndef EMS_ABLATE_ES
-    cn_core(C, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
+    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
 #else
     if (lane < 16) lens[lane < C.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
     wave_lds_sync();
@@ -905,7 +933,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 // LDS carve of a workgroup: [idx2bin Q][bin2idx Q][first-nonzero-syndrome word, task counter, pad to 16]
 // [done flags, one byte per task, padded to 16] then one region per wave: dense rows | survivors | lists |
 // lens | picks.
-__host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16 + ((M + 15) & ~15); }
+__host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16 + CN_SCHED_BYTES + ((M + 15) & ~15); }
 
 // ------------------------------------------------------------------------------------------------
 // The decode kernel: one workgroup per frame, persistent over all sweeps.
@@ -940,7 +968,8 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
     unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
     unsigned *next_task = first_bad + 1;
     unsigned *spin_fail = first_bad + 2;
-    uint8_t *done = smem + 2 * Q + 16;
+    uint2 *sched = reinterpret_cast<uint2 *>(smem + 2 * Q + 16);
+    uint8_t *done = smem + 2 * Q + 16 + CN_SCHED_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -963,6 +992,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
         t_b2i[i] = P.bin2idx[i];
     }
     for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
+    cn_sched_build(sched, C.dc, C.nm, tid, blockDim.x);
     for (int i = lane; i < 4 * Q; i += 64) tbl[i] = 0u;
     if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
@@ -1027,7 +1057,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, tbl, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, tbl, sched, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
@@ -1193,7 +1223,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     const bool g0 = lane < 8;
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
     if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
-        es_stage_fast(lists, lens, tbl, picks, q, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper, min(nbOper, nm + 3));
+        es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3));
     else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
@@ -1212,8 +1242,10 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     int *lens = reinterpret_cast<int *>(smem + ((P.n_lists * nmp * 8 + 15) & ~15));
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
     __shared__ uint8_t picks[ES_PICK_BYTES];
+    __shared__ uint2 sched[CN_SCHED_BYTES / 8];
     const int lane = threadIdx.x;
     bool big = false;
+    cn_sched_build(sched, dc, nm, lane, 64);
     for (int i = lane; i < 4 * 256; i += 64) tbl[i] = 0u;
     for (int i = lane; i < dc * nmp; i += 64) {                // rotation, bubble_decoder.c:133-152
         const int t = i / nmp, k = i - t * nmp;
@@ -1230,7 +1262,7 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     Cfg C;
     C.dc = dc; C.nm = nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, nm + 3); C.q = Q; C.nsteps = dc - 2;
     C.n_lists = P.n_lists; C.offset = P.offset;
-    cn_core(C, lists, lens, tbl, picks, lane, __ballot(big) != 0ull);
+    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
         const EmsEntry *ol = lists + oid * nmp;
