@@ -789,7 +789,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                           EmsEntry *lists, int *lens, uint8_t *picks, unsigned *tbl, const uint2 *sched, int lane
+                                           EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int lane
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -877,6 +877,11 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
 #ifndef EMS_ABLATE_ES
+    // the dense staging rows are dead until the expansion below: their first 4Q words serve as the four dedupe
+    // tables of the elementary steps, zeroed here and kept all-zero from stage to stage
+    unsigned *tbl = reinterpret_cast<unsigned *>(dense);
+    for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
+    wave_lds_sync();
     cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
 #else
     if (lane < 16) lens[lane < C.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
@@ -985,7 +990,6 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
     int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
     uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((C.n_lists * 4 + 15) & ~15);   // 8 x 68 pick bytes + 64 dummy dwords
-    unsigned *tbl = reinterpret_cast<unsigned *>(picks + ((ES_PICK_BYTES + 15) & ~15));   // 4 dedupe tables of Q words, kept all-zero between uses
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
@@ -993,7 +997,6 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
     }
     for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
     cn_sched_build(sched, C.dc, C.nm, tid, blockDim.x);
-    for (int i = lane; i < 4 * Q; i += 64) tbl[i] = 0u;
     if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
 
@@ -1057,7 +1060,7 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, tbl, sched, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
@@ -1327,7 +1330,7 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
     const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * surv_stride(lpe) * 8; // staging rows + survivor scratch
     const size_t lists = ((size_t)n_lists * list_stride(nm) * 8 + 15) & ~(size_t)15;
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens + ((ES_PICK_BYTES + 15) & ~15) + (size_t)4 * q * 4; // + pick bytes and dedupe tables of the elementary steps
+    return dense + lists + lens + ((ES_PICK_BYTES + 15) & ~15); // + pick bytes of the elementary steps (their dedupe tables alias the staging rows)
 }
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
