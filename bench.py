@@ -7,7 +7,8 @@ A "step" is one pass of the hot path over one batch of synthetic frames per GPU:
 init -> 29 layered EMS sweeps with per-sweep hard decision + syndrome -> bit-error count, inputs
 (noisy BPSK samples + transmitted codewords) already resident in HBM.  Workload at every N is
 BASELINE.json configs[3]: Ahmed_64800_R12_GF256, nm=20, NbIterMax=30 (29 sweeps, NB_LDPC.c:314),
-offset 0.3, NbOper 40, batch 256 per GPU, early exit disabled (fixed work), Eb/N0 = 1.0 dB frames drawn
+offset 0.3, NbOper 40, batch 768 per GPU (3 frames per CU), early exit disabled (fixed work),
+Eb/N0 = 1.0 dB frames drawn
 from the reference harness' own drand48 stream (each rank jumps the LCG to its frame range).  Frames are
 independent, so ranks share nothing on the data path ("scaling": "weak"); per step the ranks all-reduce
 the five error counters over RCCL, as the Monte-Carlo harness does.
@@ -30,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (matrix, nm, NbOper, offset, NbIterMax, EbN0 for fixed work, default batch)
-    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 256),
+    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 768),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
 }
@@ -86,9 +87,6 @@ def main():
     ap.add_argument("--workload", default="gf256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="batches decoded concurrently per GPU (own handle + stream each, 4 waves per frame when > 1); "
-                         "the default 1 is the BASELINE configuration, >1 is the Monte-Carlo throughput mode")
     ap.add_argument("--synthetic-zero-codeword", action="store_true",
                     help="skip the host encoder: all-zero codeword + numpy AWGN (faster set-up, same work)")
     a = ap.parse_args()
@@ -114,10 +112,7 @@ def main():
     B = a.batch or B0
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)
-    if a.inflight > 1:
-        os.environ.setdefault("EMS_WAVES", "4")     # 3 workgroups of 4 waves fit one CU; see DESIGN.md section 5
     dec = pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False)
-    extra = [pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False) for _ in range(a.inflight - 1)]
 
     # ---- synthetic inputs, staged in HBM before the timed region ----
     t_setup = time.time()
@@ -138,23 +133,11 @@ def main():
     pkg._check(pkg.lib().ems_llr_init(dec.h, pkg._ptr(noisy), np.float32(sigma), B))  # uploads into the staging buffer
     dec.set_codewords(cws)
     dec.synchronize()
-    for d in extra:                                 # the other in-flight batches decode the same frames
-        pkg._check(pkg.lib().ems_llr_init(d.h, pkg._ptr(noisy), np.float32(sigma), B))
-        d.set_codewords(cws)
-        d.synchronize()
     noisy_dev = dec.noisy_dev_ptr
     counters = torch.zeros(5, dtype=torch.int64, device="cuda")
 
     def step():
-        for d in extra:                             # every batch's LLR init first, then the persistent decode kernels
-            d.llr_init_dev(d.noisy_dev_ptr, sigma, B)     # back to back so that they become co-resident on the CUs
         dec.llr_init_dev(noisy_dev, sigma, B)
-        if extra:                                   # 3 x 256 workgroups fill the 256 CUs exactly: dispatch them onto idle CUs
-            for d in extra:
-                d.synchronize()
-            dec.synchronize()
-        for d in extra:
-            d.decode(B)
         dec.decode(B)
         nberr = dec.count_errors_resident(B)                      # syncs the decoder's stream
         _d, iters, synd = None, None, None
@@ -162,8 +145,6 @@ def main():
         pkg._check(pkg.lib().ems_get_results(dec.h, B, None, pkg._ptr(it), pkg._ptr(sy)))
         loc = torch.tensor([B, int((nberr != 0).sum()), int(nberr.sum()), int(((nberr != 0) & (sy == 0)).sum()), int(it.sum())],
                            dtype=torch.int64)
-        for d in extra:
-            d.count_errors_resident(B)
         counters.copy_(loc)
         if dist is not None:
             dist.all_reduce(counters)                             # RCCL, 40 bytes
@@ -192,38 +173,8 @@ def main():
         dt = float(t.item())
     tot = counters.cpu().tolist()
 
-    thr = None
-    if world == 1 and a.inflight == 1 and a.workload == "gf256" and not os.environ.get("EMS_BENCH_NO_THROUGHPUT_MODE"):
-        # Monte-Carlo throughput mode, reported beside (never instead of) `value`: three batches of 256 frames in
-        # flight (own handle + stream each, 4 waves per frame, so that three workgroups share a CU).
-        dec.close()
-        os.environ["EMS_WAVES"] = "4"
-        ds = [pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False) for _ in range(3)]
-        del os.environ["EMS_WAVES"]
-        for d in ds:
-            pkg._check(pkg.lib().ems_llr_init(d.h, pkg._ptr(noisy), np.float32(sigma), B))
-            d.synchronize()
-
-        def tstep():
-            for d in ds:
-                d.llr_init_dev(d.noisy_dev_ptr, sigma, B)
-            for d in ds:
-                d.synchronize()
-            for d in ds:
-                d.decode(B)
-            for d in ds:
-                d.synchronize()
-
-        tstep()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            tstep()
-        thr = 3 * B * 2 / (time.perf_counter() - t1)
-        for d in ds:
-            d.close()
-        dec = None
     if rank == 0:
-        value = world * B * a.inflight * a.steps / dt
+        value = world * B * a.steps / dt
         sweeps = itmax - 1
         alg = algorithmic_bytes_per_frame_decode(code.E, code.GF, nm, sweeps) * B
         kavg = float(np.mean(kms)) * 1e-3
@@ -236,22 +187,20 @@ def main():
             "dtype": "f32", "data": data,
             "config": {"workload": "%s nm=%d NbIterMax=%d (%d sweeps) offset=%.1f NbOper=%d, fixed work (early exit off)"
                                    % (mat, nm, itmax, sweeps, off, nop),
-                       "batch_per_gpu": B, "batches_in_flight_per_gpu": a.inflight, "sharding": "independent frames, contiguous batches per rank",
+                       "batch_per_gpu": B, "sharding": "independent frames, contiguous batches per rank",
                        "collective": "all-reduce of 5 int64 error counters per step" if world > 1 else "none",
                        "frames_errframes_biterrs_undetected_sumiter": tot},
-            "roofline": {"bound": "hbm", "kernel": "k_decode (persistent, 1 workgroup per frame)",
+            "roofline": {"bound": "hbm", "kernel": "k_decode (persistent, 1 workgroup per frame, %d frames per launch)" % B,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3),
                          "llr_init_avg_ms": round(float(np.mean(lms)), 3)},
             "host_setup_s": round(t_setup, 1),
         }
-        if thr is not None:
-            out["config"]["throughput_mode_3_batches_in_flight_frames_per_s"] = round(thr, 1)
         tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tr):
             try:
-                out["roofline"]["traffic"] = json.load(open(tr))["hbm_bytes_per_launch"]
+                out["roofline"]["traffic"] = int(json.load(open(tr))["hbm_bytes_per_frame"] * B)   # measured per launch / frames
             except Exception:
                 pass
         if world == 1 and not a.no_cpu_baseline:
@@ -259,10 +208,7 @@ def main():
             threads = max(1, min(os.cpu_count() or 1, 16))
             out["cpu_baseline"] = cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads)
         print(json.dumps(out), flush=True)
-    if dec is not None:
-        dec.close()
-    for d in extra:
-        d.close()
+    dec.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -177,7 +177,7 @@ template <typename T> struct DevBuf {
 } // namespace
 
 struct ems_handle {
-    int device = 0, max_batch = 0, nm_alloc = 0;
+    int device = 0, max_batch = 0, nm_alloc = 0, n_cu = 0;
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp;
@@ -356,6 +356,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
 
     ems_handle *h = new ems_handle;
     h->device = device; h->max_batch = max_batch; h->nm_alloc = prm->nm; h->prm = *prm;
+    (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);
     auto bail = [&](int code) { ems_destroy(h); return code; };
@@ -494,12 +495,32 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
     return EMS_OK;
 }
 
+// Workgroup shape of one launch.  A frame is a chain of dependent check-node visits, so one frame per CU
+// (12 waves) leaves the SIMDs idle about a third of the time; with more frames than CUs the dc <= 4
+// kernels (12 waves of 170 VGPRs per CU) run several smaller workgroups per CU instead -- 3 frames of 4
+// waves or 6 frames of 2 waves, shapes that put the same number of waves of every workgroup on each SIMD
+// (a 6-wave workgroup does not: two of them cannot share a CU).  The 2-wave form is used only when the
+// batch fills it (6 frames per CU).  Other kernels keep the plan's shape.
+static int waves_for_batch(const ems_handle *h, int B)
+{
+    const int w0 = h->plan.waves_per_wg;
+    if (getenv("EMS_WAVES") || ems_max_waves_for(h->dc) != 12 || w0 < 12 || h->n_cu <= 0) return w0;
+    const size_t lds_cap = 160 * 1024;
+    auto fits = [&](int w) { return (size_t)(12 / w) * ems_wg_lds_bytes(h->q, h->M, h->plan.wave_lds_bytes, w) <= lds_cap; };
+    const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
+    if (fpc >= 6 && fits(2)) return 2;
+    if (fpc >= 2 && fits(4)) return 4;
+    return w0;
+}
+
 int ems_decode(ems_handle *h, int B)
 {
     int r = check_batch(h, B);
     if (r) return r;
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-    HIP_TRY(ems_launch_decode(h->plan, B, h->stream));
+    EmsPlan P = h->plan;
+    P.waves_per_wg = waves_for_batch(h, B);
+    HIP_TRY(ems_launch_decode(P, B, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->have_dec_ev = true;
     return EMS_OK;
