@@ -225,59 +225,6 @@ __device__ __forceinline__ unsigned red8_minu(unsigned x)
     return x;
 }
 
-template <int NJ>
-__device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
-                                        const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
-                                        int nbOper, int &S_out)
-{
-    // tbl is all-zero on entry (and left all-zero: every claimed entry is cleared again below)
-    wave_lds_sync();
-    float val[NJ];
-    unsigned sym[NJ];
-    int lim = 1 << 20;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
-        const bool ok = has && i < T;
-        const unsigned pk = picks[ok ? i : 0];
-        const int w = pk >> 5, k = pk & 31;
-        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
-        const EmsEntry e1 = in1[r], e2 = in2[c];
-        val[j] = e1.v + e2.v;
-        const unsigned sy = sym_comb(e1.s, e2.s);
-        sym[j] = sy & 0xFFu;
-        const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
-        lim = min(lim, li);
-    }
-    lim = red8_mini(lim);
-    const bool stopped = lim <= T;
-    lim = min(lim, T);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
-        if (has && i < lim) atomicMax(&tbl[sym[j]], (unsigned)(ES_MAX_STEPS - i));
-    }
-    wave_lds_sync();
-    int base = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
-        const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
-        const int sidx = base + __popc(m8 & ((1u << p) - 1u));
-        if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
-        base += __popc(m8);
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-        if (has && p + 8 * j < lim) tbl[sym[j]] = 0u;
-    S_out = min(base, nm);
-    return (base >= nm) || stopped || (T >= nbOper);
-}
-
-
 // Register-light form of es_post for the rare continuation (T up to 64 picks): same algorithm, the
 // per-pick value/symbol are recomputed in each of the three passes instead of being kept in registers.
 __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
@@ -390,6 +337,96 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
     if (ss < to) step(a0, a1, ss);
 }
 
+// Post-pass of the first T picks of a stage (T <= 8 NJ): stop rules, first-occurrence dedupe through the
+// symbol table, ordered compaction into `out`.  When some group has neither nm outputs nor a stop yet (about
+// one stage in ten at nm = 20: duplicates eat picks), the merge runs 8 more steps with the exact rule and the
+// new picks go through the same table incrementally -- its first-pass claims are still in place, and a later
+// pick never displaces an earlier one (ds_max of ES_MAX_STEPS - i).  tbl is all-zero on entry and on exit.
+template <int NJ>
+__device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
+                                        uint8_t *picks, uint8_t *dummy, int q, int p, int gbase, bool has, int T, int nm,
+                                        int nbOper, int &S_out, unsigned &hv, int &y, float fxv, const EmsEntry *mvy, int &T_done)
+{
+    wave_lds_sync();
+    float val[NJ];
+    unsigned sym[NJ];
+    int lim = 1 << 20;
+    auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &li) {
+        const unsigned pk = picks[ok ? i : 0];
+        const int w = pk >> 5, k = pk & 31;
+        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
+        const EmsEntry e1 = in1[r], e2 = in2[c];
+        v = e1.v + e2.v;
+        sy = sym_comb(e1.s, e2.s);
+        li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
+        sy &= 0xFFu;
+    };
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        int li;
+        gather(i, has && i < T, val[j], sym[j], li);
+        lim = min(lim, li);
+    }
+    lim = red8_mini(lim);
+    bool stopped = lim <= T;
+    lim = min(lim, T);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        if (has && i < lim) atomicMax(&tbl[sym[j]], (unsigned)(ES_MAX_STEPS - i));
+    }
+    wave_lds_sync();
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = p + 8 * j;
+        const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const int sidx = base + __popc(m8 & ((1u << p) - 1u));
+        if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
+        base += __popc(m8);
+    }
+    bool done = (base >= nm) || stopped || (T >= nbOper);
+    T_done = T;
+    bool clrx = false;
+    unsigned symx = 0;
+    if (__ballot(has && !done) != 0ull) {
+        DBG_ADD(4, 1);
+        const int T2 = min(T + 8, nbOper);
+        es_merge<true>(hv, y, fxv, mvy, picks, dummy, p, gbase, T, T2);
+        T_done = T2;
+        wave_lds_sync();
+        const int i = T + p;
+        const bool ok = has && !done && i < T2;
+        float v;
+        int li;
+        gather(i, ok, v, symx, li);
+        int lim2 = red8_mini(li);
+        const bool stopped2 = lim2 <= T2;
+        lim2 = min(lim2, T2);
+        clrx = ok && i < lim2;
+        if (clrx) atomicMax(&tbl[symx], (unsigned)(ES_MAX_STEPS - i));
+        wave_lds_sync();
+        const bool u = clrx && tbl[symx] == (unsigned)(ES_MAX_STEPS - i);
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const int sidx = base + __popc(m8 & ((1u << p) - 1u));
+        if (u && sidx < nm) out[sidx] = EmsEntry{v, symx};
+        if (!done) {
+            base += __popc(m8);
+            done = (base >= nm) || stopped2 || (T2 >= nbOper);
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (has && p + 8 * j < lim) tbl[sym[j]] = 0u;
+    if (clrx) tbl[symx] = 0u;
+    S_out = min(base, nm);
+    return done;
+}
+
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
                                               int lane, uint2 task, int nm, int nbOper, int T1)
 {
@@ -428,19 +465,20 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     bool done;
     init();
     es_merge<false>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
+    DBG_ADD(3, 1);
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
+        DBG_ADD(5, 1);
         init();
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
-#ifdef EMS_DUP_POST   /* timing experiment: the post-pass twice (idempotent) */
-    if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
-#endif
-    if (T1 <= 16) done = es_post<2>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
-    else if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    int Td = T1;   // picks merged so far
+    if (T1 <= 16) done = es_post<2>(in1, in2, out, tbl, picks, dummy, q, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, dummy, q, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
     else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
-        // rare: neither nm outputs nor a stop within the first nm+3 picks -> merge on up to nbOper
-        es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, T1, nbOper);
+        // rare: neither nm outputs nor a stop within the first nm+3 (+8) picks -> merge on up to nbOper
+        DBG_ADD(6, 1);
+        es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
         es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
     }
     if (has && p == 0) lens[o_id] = S;
@@ -962,7 +1000,10 @@ __global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q
     C.dc = DC > 0 ? DC : P.dc;
     C.nm = NM > 0 ? NM : P.nm;
     C.nbOper = P.nbOper;
-    C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
+#ifndef EMS_T1_EXTRA
+#define EMS_T1_EXTRA 3
+#endif
+    C.T1 = NM > 0 ? NM + EMS_T1_EXTRA : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
     C.q = Q;
     C.nsteps = C.dc - 2;
     C.n_lists = C.dc + 3 * (C.dc - 2);
