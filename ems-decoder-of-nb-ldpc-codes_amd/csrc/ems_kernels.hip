@@ -664,12 +664,24 @@ __device__ __forceinline__ unsigned mono_key(float v)
 // compare + select costs three issue slots with the VCC hazard).  Not volatile: the compiler may schedule it.
 __device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// one butterfly step min/max(x, x from the partner lane) as a single DPP instruction.  Inline asm is opaque to
+// the hazard recogniser, so the two wait states a DPP read needs after the VALU write of its source are spelt out.
+#define EMS_DPP_MM(op, ctl) asm("s_nop 1\n\t" op " %0, %1, %1 " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x))
+template <int CTRL, bool MAX> __device__ __forceinline__ float dpp_minmax_f(float x)
+{
+    float r;
+    if (CTRL == DPP_XOR1) { if (MAX) EMS_DPP_MM("v_max_f32_dpp", "quad_perm:[1,0,3,2]"); else EMS_DPP_MM("v_min_f32_dpp", "quad_perm:[1,0,3,2]"); }
+    else if (CTRL == DPP_XOR2) { if (MAX) EMS_DPP_MM("v_max_f32_dpp", "quad_perm:[2,3,0,1]"); else EMS_DPP_MM("v_min_f32_dpp", "quad_perm:[2,3,0,1]"); }
+    else if (CTRL == DPP_HMIRROR) { if (MAX) EMS_DPP_MM("v_max_f32_dpp", "row_half_mirror"); else EMS_DPP_MM("v_min_f32_dpp", "row_half_mirror"); }
+    else { if (MAX) EMS_DPP_MM("v_max_f32_dpp", "row_mirror"); else EMS_DPP_MM("v_min_f32_dpp", "row_mirror"); }
+    return r;
+}
 template <int LPE, bool MAX> __device__ __forceinline__ float row_minmax_f(float x)
 {
-    x = MAX ? vmaxf(x, dpp_f<DPP_XOR1>(x)) : vminf(x, dpp_f<DPP_XOR1>(x));
-    x = MAX ? vmaxf(x, dpp_f<DPP_XOR2>(x)) : vminf(x, dpp_f<DPP_XOR2>(x));
-    if (LPE >= 8) x = MAX ? vmaxf(x, dpp_f<DPP_HMIRROR>(x)) : vminf(x, dpp_f<DPP_HMIRROR>(x));
-    if (LPE == 16) x = MAX ? vmaxf(x, dpp_f<DPP_MIRROR>(x)) : vminf(x, dpp_f<DPP_MIRROR>(x));
+    x = dpp_minmax_f<DPP_XOR1, MAX>(x);
+    x = dpp_minmax_f<DPP_XOR2, MAX>(x);
+    if (LPE >= 8) x = dpp_minmax_f<DPP_HMIRROR, MAX>(x);
+    if (LPE == 16) x = dpp_minmax_f<DPP_MIRROR, MAX>(x);
     return x;
 }
 
@@ -710,13 +722,14 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     // ---- A ----
     float lmin = mvc[0];
 #pragma unroll
-    for (int e = 1; e < G::EPL; ++e) lmin = (mvc[e] < lmin) ? mvc[e] : lmin;
-    const float rmin = row_reduce_f<LPE>(lmin, [](float a, float b) { return a < b; });
+    for (int e = 1; e < G::EPL; ++e) lmin = vminf(mvc[e], lmin);
+    const float rmin = row_minmax_f<LPE, false>(lmin);
     float T = __builtin_inff();
     int cnt = Q;
+    int lc = G::EPL;     // this lane's survivors under the final T
     bool done = true;
     if (Q > SEL_CAP) {
-        const float rmaxl = row_reduce_f<LPE>(lmin, [](float a, float b) { return a > b; });
+        const float rmaxl = row_minmax_f<LPE, true>(lmin);
         float lo = rmin, hi = rmaxl;
         int clo = 1, chi = 0;
         bool hiv = false;
@@ -727,6 +740,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
             int c = 0;
 #pragma unroll
             for (int e = 0; e < G::EPL; ++e) c += (mvc[e] <= T) ? 1 : 0;
+            lc = c;                          // (a finished row keeps its T, so the recount is the same number)
             c = row_sum_i<LPE>(c);
             if (!done) {
                 cnt = c;
@@ -756,9 +770,6 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     T_out = T;
 
     // ---- B ----
-    int lc = 0;
-#pragma unroll
-    for (int e = 0; e < G::EPL; ++e) lc += (mvc[e] <= T) ? 1 : 0;
     int off = row_excl_scan_i<LPE>(lc, rl);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) {
