@@ -769,58 +769,69 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     if (__ballot(!done) != 0ull) { DBG_ADD(2, 1); return false; }
     T_out = T;
 
-    // ---- B ----
+    // ---- B ----  survivors as two arrays (values | symbols) so that the ranking reads four values per LDS access
+    float *svals = reinterpret_cast<float *>(surv);
+    unsigned *ssyms = reinterpret_cast<unsigned *>(surv) + (SEL_CAP + LPE);
     int off = row_excl_scan_i<LPE>(lc, rl);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) {
         const bool sv = mvc[e] <= T;
-        surv[sv ? off : SEL_CAP + rl] = EmsEntry{mvc[e], (unsigned)G::sym_of(e, rl)};
+        const int slot = sv ? off : SEL_CAP + rl;                       // non-survivors land in this lane's dummy slot
+        svals[slot] = mvc[e];
+        ssyms[slot] = (unsigned)G::sym_of(e, rl);
         off += sv ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {                                     // slots cnt..SEL_CAP-1 never count as smaller
+        const int idx = rl + k * LPE;
+        svals[idx >= cnt ? idx : SEL_CAP + rl] = __builtin_inff();
     }
     wave_lds_sync();
 
-    // ---- C ----
-    EmsEntry my[SPL];
-    unsigned long long key[SPL];
-    int rank[SPL];
+    // ---- C ----  rank = number of strictly smaller survivors, from the sign bits of (v_j - v_i).  Exact unless
+    // two survivors compare equal (the reference then takes the lower symbol first) or a -0 is present: both are
+    // detected (ranks of a row must add up to cnt(cnt-1)/2) and sent to the literal path.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float myv[SPL];
+    unsigned mys[SPL], acc[SPL];
+    bool odd = false;
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int idx = rl + k * LPE;
-        const bool valid = idx < cnt;
-        my[k] = surv[idx];
-        key[k] = valid ? (((unsigned long long)mono_key(my[k].v) << 32) | my[k].s) : ~0ull;
-        rank[k] = valid ? 0 : 0x7FFF;
+        myv[k] = svals[idx];
+        mys[k] = ssyms[idx];
+        acc[k] = 0u;
+        odd = odd || (idx < cnt && __float_as_uint(myv[k]) == 0x80000000u);
     }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {
-        const int idx = rl + k * LPE;
-        *reinterpret_cast<unsigned long long *>(&surv[idx]) = key[k];   // mono keys; slots >= cnt get the max key
-    }
-    wave_lds_sync();
-    // all SEL_CAP slots hold a key (slots >= cnt the maximal one), so the rank loop has a fixed trip count;
-    // the keys are fetched four at a time so that the LDS latency is paid once per batch, not per key
 #pragma unroll
     for (int j0 = 0; j0 < (Q < SEL_CAP ? Q : SEL_CAP); j0 += 4) {
-        unsigned long long kj[4];
+        const float4 vj = *reinterpret_cast<const float4 *>(svals + j0);
 #pragma unroll
-        for (int u = 0; u < 4; u += 2) {
-            const uint4 two = *reinterpret_cast<const uint4 *>(&surv[j0 + u]);
-            kj[u] = ((unsigned long long)two.y << 32) | two.x;
-            kj[u + 1] = ((unsigned long long)two.w << 32) | two.z;
+        for (int k = 0; k < SPL; ++k) {
+            const v2f me = {myv[k], myv[k]};
+            const v2f dl = v2f{vj.x, vj.y} - me, dh = v2f{vj.z, vj.w} - me;
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dl.x), 31);     // acc = acc << 1 | sign
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dl.y), 31);
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dh.x), 31);
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dh.y), 31);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < SPL; ++k) rank[k] += (kj[u] < key[k]) ? 1 : 0;
     }
+    int rank[SPL], rsum = 0;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const bool valid = rl + k * LPE < cnt;
+        rank[k] = valid ? __popc(acc[k]) : 0x7FFF;
+        rsum += valid ? rank[k] : 0;
+    }
+    rsum = row_sum_i<LPE>(rsum);
+    if (__ballot(odd || 2 * rsum != cnt * (cnt - 1)) != 0ull) { DBG_ADD(2, 1); return false; }
     const float v0 = rmin < EMS_SENTINEL ? rmin : EMS_SENTINEL;         // the first selected value
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         if (rowact && rank[k] < nm) {
-            const bool ok = my[k].v < EMS_SENTINEL;                     // NB_LDPC.c:358-366
-            const float v = ok ? my[k].v : EMS_SENTINEL;
-            const int g = ok ? (int)my[k].s : 0;
+            const bool ok = myv[k] < EMS_SENTINEL;                      // NB_LDPC.c:358-366
+            const float v = ok ? myv[k] : EMS_SENTINEL;
+            const int g = ok ? (int)mys[k] : 0;
             const int gi = gf_mul_log(g, lh, Q - 1);
             const float nv = rank[k] == 0 ? 0.0f : v - v0;
             big = big || !(nv < 1e4f);
