@@ -770,8 +770,14 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     T_out = T;
 
     // ---- B ----  survivors as two arrays (values | symbols) so that the ranking reads four values per LDS access
-    float *svals = reinterpret_cast<float *>(surv);
-    unsigned *ssyms = reinterpret_cast<unsigned *>(surv) + (SEL_CAP + LPE);
+    // (the row base goes through an opaque register so that the 16 compaction stores address it with their small
+    //  immediate offsets instead of re-adding the wave-relative constant each time)
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    unsigned srow = (unsigned)(uintptr_t)(lds_f32 *)reinterpret_cast<float *>(surv);
+    asm volatile("" : "+v"(srow));
+    lds_f32 *svals = (lds_f32 *)(uintptr_t)srow;
+    lds_u32 *ssyms = (lds_u32 *)(uintptr_t)srow + (SEL_CAP + LPE);
     int off = row_excl_scan_i<LPE>(lc, rl);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) {
@@ -805,7 +811,8 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     }
 #pragma unroll
     for (int j0 = 0; j0 < (Q < SEL_CAP ? Q : SEL_CAP); j0 += 4) {
-        const float4 vj = *reinterpret_cast<const float4 *>(svals + j0);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f vj = *(const __attribute__((address_space(3))) v4f *)(svals + j0);
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
             const v2f me = {myv[k], myv[k]};
