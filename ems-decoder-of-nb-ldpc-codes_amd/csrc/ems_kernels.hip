@@ -313,28 +313,46 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
     // its updated position; the step after next picks the element of that pair its predecessor's outcome
     // (advance or not) makes current.  Two pairs alternate, each reloaded by the step that consumed it.
     // mvy = mv - 32 p entries, i.e. mvy[y] == mv[pos].
-    float a0 = mvy[y + 1].v, a1 = mvy[y + 2].v;
+    // The list address is recomputed from y with one shift-add per step (opaque to the optimiser, which would
+    // otherwise carry y and the address as two separate induction variables at one more instruction per step).
+    typedef __attribute__((address_space(3))) const float lds_cf32;
+    const unsigned mvb = (unsigned)(uintptr_t)(lds_cf32 *)&mvy[0].v;
+    auto at = [&](int yy) { unsigned a; asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a) : "v"(yy), "v"(mvb)); return (lds_cf32 *)(uintptr_t)a; };
+    lds_cf32 *q0 = at(y);
+    float a0 = q0[2], a1 = q0[4];
     float b0 = a0, b1 = a1;
     bool wprev = false;
     auto step = [&](float &x0, float &x1, int ss) {
         const unsigned m = red8_minu(hv);
         bool iw = (hv == m);
         if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
+#ifndef EMS_NO_PREFETCH2
         const float nx = wprev ? x1 : x0;
+#else
+        const float nx = x0;
+#endif
         (iw ? pk : dummy)[ss] = (uint8_t)y;      // losers write to their own dummy dword (+ss: still one dword per lane)
         y += iw ? 1 : 0;
+        asm("" : "+v"(y));                    // one add-with-carry per step (no re-association across steps)
         hv = iw ? (unsigned)__float_as_int(fxv + nx) : hv;
-        x0 = mvy[y + 1].v;
-        x1 = mvy[y + 2].v;
+        lds_cf32 *qn = at(y);
+        x0 = qn[2];
+#ifndef EMS_NO_PREFETCH2
+        x1 = qn[4];
         wprev = iw;
+#endif
     };
     int ss = from;
 #pragma unroll
+#ifndef EMS_NO_PREFETCH2
     for (; ss + 1 < to; ss += 2) {
         step(a0, a1, ss);
         step(b0, b1, ss + 1);
     }
     if (ss < to) step(a0, a1, ss);
+#else
+    for (; ss < to; ++ss) step(a0, a1, ss);
+#endif
 }
 
 // Post-pass of the first T picks of a stage (T <= 8 NJ): stop rules, first-occurrence dedupe through the
