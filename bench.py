@@ -7,7 +7,7 @@ A "step" is one pass of the hot path over one batch of synthetic frames per GPU:
 init -> 29 layered EMS sweeps with per-sweep hard decision + syndrome -> bit-error count, inputs
 (noisy BPSK samples + transmitted codewords) already resident in HBM.  Workload at every N is
 BASELINE.json configs[3]: Ahmed_64800_R12_GF256, nm=20, NbIterMax=30 (29 sweeps, NB_LDPC.c:314),
-offset 0.3, NbOper 40, batch 768 per GPU (3 frames per CU), early exit disabled (fixed work),
+offset 0.3, NbOper 40, batch 1024 per GPU (4 frames per CU), early exit disabled (fixed work),
 Eb/N0 = 1.0 dB frames drawn
 from the reference harness' own drand48 stream (each rank jumps the LCG to its frame range).  Frames are
 independent, so ranks share nothing on the data path ("scaling": "weak"); per step the ranks all-reduce
@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (matrix, nm, NbOper, offset, NbIterMax, EbN0 for fixed work, default batch)
-    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 768),
+    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1024),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
 }

@@ -224,6 +224,7 @@ int refresh_plan(ems_handle *h)
     while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
     if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
     P.waves_per_wg = waves;
+    P.occ4 = 0;
     P.stamps = h->d_stamps.p;
     return EMS_OK;
 }
@@ -497,20 +498,18 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
 
 // Workgroup shape of one launch.  A frame is a chain of dependent check-node visits, so one frame per CU
 // (12 waves) leaves the SIMDs idle about a third of the time; with more frames than CUs the dc <= 4
-// kernels (12 waves of 170 VGPRs per CU) run several smaller workgroups per CU instead -- 3 frames of 4
-// waves or 6 frames of 2 waves, shapes that put the same number of waves of every workgroup on each SIMD
-// (a 6-wave workgroup does not: two of them cannot share a CU).  The 2-wave form is used only when the
-// batch fills it (6 frames per CU).  Other kernels keep the plan's shape.
-static int waves_for_batch(const ems_handle *h, int B)
+// kernels run several 4-wave workgroups per CU instead (one wave of every workgroup on each SIMD; a 6-wave
+// workgroup would not spread evenly and two of them cannot share a CU): 3 frames per CU with the ~143-VGPR
+// build, 4 with the 128-VGPR build where it exists and the batch fills it.  Other kernels keep the plan's shape.
+static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P)
 {
-    const int w0 = h->plan.waves_per_wg;
-    if (getenv("EMS_WAVES") || ems_max_waves_for(h->dc) != 12 || w0 < 12 || h->n_cu <= 0) return w0;
-    const size_t lds_cap = 160 * 1024;
-    auto fits = [&](int w) { return (size_t)(12 / w) * ems_wg_lds_bytes(h->q, h->M, h->plan.wave_lds_bytes, w) <= lds_cap; };
+    P.occ4 = 0;
+    if (getenv("EMS_WAVES")) { P.occ4 = getenv("EMS_OCC4") ? 1 : 0; return; }     // developer knobs
+    if (ems_max_waves_for(h->dc) != 12 || P.waves_per_wg < 12 || h->n_cu <= 0) return;
+    const size_t lds_cap = 160 * 1024, wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
-    if (fpc >= 6 && fits(2)) return 2;
-    if (fpc >= 2 && fits(4)) return 4;
-    return w0;
+    if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
+    else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }
 
 int ems_decode(ems_handle *h, int B)
@@ -519,7 +518,7 @@ int ems_decode(ems_handle *h, int B)
     if (r) return r;
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     EmsPlan P = h->plan;
-    P.waves_per_wg = waves_for_batch(h, B);
+    shape_for_batch(h, B, P);
     HIP_TRY(ems_launch_decode(P, B, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->have_dec_ev = true;

@@ -10,6 +10,7 @@ int ems_lpe_for(int dc);                                     // lanes per edge r
 int ems_max_waves_for(int dc);                             // waves per workgroup the kernel is built for
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
+bool ems_has_occ4_kernel(const EmsPlan &P);
 
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,

@@ -1038,9 +1038,11 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // deadlock; the spin is bounded anyway.  Sweeps are separated by __syncthreads() (Decision + Syndrom
 // need the whole sweep, NB_LDPC.c:468-471).
 // ------------------------------------------------------------------------------------------------
-template <int Q, int LPE, int DC, int NM>
+// OCC4: the build of a dc <= 4 kernel for four 4-wave workgroups per CU (128 VGPRs instead of ~143; the
+// register allocator pays a few moves for it, so the 12-wave-per-CU shapes keep the roomier build).
+template <int Q, int LPE, int DC, int NM, bool OCC4 = false>
 // (the small GF(64)/dc=4 specialisation runs many 2-wave workgroups per CU: ask for 4 waves per SIMD there)
-__global__ void __launch_bounds__((LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (Q == 64 && DC == 4) ? 4 : 1) k_decode(const EmsPlan P)
+__global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (OCC4 || (Q == 64 && DC == 4)) ? 4 : 1) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
     Cfg C;
@@ -1423,23 +1425,27 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
 
-template <int Q, int LPE, int DC = 0, int NM = 0> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
+template <int Q, int LPE, int DC = 0, int NM = 0, bool OCC4 = false> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
 {
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode<Q, LPE, DC, NM>, lds);
+    hipError_t e = set_max_lds(k_decode<Q, LPE, DC, NM, OCC4>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_decode<Q, LPE, DC, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipLaunchKernelGGL((k_decode<Q, LPE, DC, NM, OCC4>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
+static bool spec_ok(const EmsPlan &P) { return P.nbOper >= P.nm + 3 && P.nbOper <= 64; }
+// kernels that also exist in the 16-waves-per-CU build
+bool ems_has_occ4_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == 4 && P.nm == 20; }
 
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
 {
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
-    const bool spec_ok = P.nbOper >= P.nm + 3 && P.nbOper <= 64;
-    if (spec_ok && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);
-    if (spec_ok && P.q == 64 && P.dc == 4 && P.nm == 16) return launch_decode_t<64, 16, 4, 16>(P, B, st);
-    if (spec_ok && P.q == 16 && P.dc == 8 && P.nm == 8) return launch_decode_t<16, 8, 8, 8>(P, B, st);
+    const bool spec = spec_ok(P);
+    if (P.occ4 && P.waves_per_wg <= 4 && ems_has_occ4_kernel(P)) return launch_decode_t<256, 16, 4, 20, true>(P, B, st);
+    if (spec && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);
+    if (spec && P.q == 64 && P.dc == 4 && P.nm == 16) return launch_decode_t<64, 16, 4, 16>(P, B, st);
+    if (spec && P.q == 16 && P.dc == 8 && P.nm == 8) return launch_decode_t<16, 8, 8, 8>(P, B, st);
     if (lpe == 16) {
         if (P.q == 256) return launch_decode_t<256, 16>(P, B, st);
         if (P.q == 64) return launch_decode_t<64, 16>(P, B, st);

@@ -63,5 +63,6 @@ struct EmsPlan {
     int rec_bytes;
     int wave_lds_bytes;     // LDS per wave
     int waves_per_wg;
+    int occ4;               // launch the 128-VGPR build (four 4-wave workgroups per CU), see ems_core.cpp waves_for_batch
     unsigned long long *stamps; // diagnostic builds only (EMS_STAMPS), else null
 };
