@@ -285,6 +285,43 @@ def test_full_size_headline_batch256_properties(pkg, orc):
     dec.close()
 
 
+@pytest.mark.parametrize("waves,occ4", [(4, False), (4, True), (2, False)])
+def test_decode_gf256_small_workgroup_shapes_vs_oracle(pkg, orc, monkeypatch, waves, occ4):
+    """The shapes the library picks for batches of several frames per CU (4-wave workgroups, and the
+    128-VGPR build of the kernel for four of them per CU), forced here on a batch the oracle can follow."""
+    monkeypatch.setenv("EMS_WAVES", str(waves))
+    if occ4:
+        monkeypatch.setenv("EMS_OCC4", "1")
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.6, 4)
+    assert list(it) == [30, 30, 30, 25]
+
+
+def test_full_size_headline_batch1024_shapes_agree(pkg, orc):
+    """BASELINE batch of the bench (1024 frames = 4 per CU, fixed work at 1.0 dB): the 128-VGPR 4-wave
+    launch must give, frame for frame, what the one-frame-per-CU launch gives (hard decisions, syndromes,
+    APP and C->V state of sampled frames); 8 distinct frames, so copies must also agree among themselves."""
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = orc.Oracle(path)
+    sigma = o.sigma(1.0)
+    rng = orc.Rng(0)
+    base = [o.draw_frame(rng, sigma) for _ in range(8)]
+    idx = np.arange(1024) % 8
+    noisy = np.stack([base[i][1] for i in idx])
+    code = pkg.Code(path)
+    big = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=1024, early_exit=False)
+    d, it, sy = big.decode_batch(noisy, sigma)
+    small = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=8, early_exit=False)
+    d8, it8, sy8 = small.decode_batch(noisy[:8], sigma)
+    for b in range(1024):
+        assert (d[b] == d8[b % 8]).all() and sy[b] == sy8[b % 8] and it[b] == it8[b % 8]
+    for b in (0, 5, 517, 1023):
+        assert big.app(b).tobytes() == small.app(b % 8).tobytes()
+        assert big.ctov(b).tobytes() == small.ctov(b % 8).tobytes()
+    ref = o.decode(o.llr(noisy[3], sigma), 20, 40, 0.3, 6, early_exit=False, want_state=True)
+    assert big.app(3).tobytes() == ref["app"].tobytes() and (d[3] == ref["decide"]).all()
+    big.close(); small.close()
+
+
 def test_full_size_n96_batch8192(pkg, orc):
     path = os.path.join(MAT, "N96_K48_GF64")
     o = orc.Oracle(path)
