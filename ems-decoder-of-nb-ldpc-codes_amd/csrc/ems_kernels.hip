@@ -694,6 +694,25 @@ template <int CTRL, bool MAX> __device__ __forceinline__ float dpp_minmax_f(floa
     else { if (MAX) EMS_DPP_MM("v_max_f32_dpp", "row_mirror"); else EMS_DPP_MM("v_min_f32_dpp", "row_mirror"); }
     return r;
 }
+__device__ __forceinline__ float vmin3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// minimum of a register array, two elements per instruction
+template <int N> __device__ __forceinline__ float array_min_f(const float (&x)[N])
+{
+    float m = x[0];
+    int e = 1;
+#pragma unroll
+    for (; e + 1 < N; e += 2) m = vmin3f(m, x[e], x[e + 1]);
+    if (e < N) m = vminf(m, x[e]);
+    return m;
+}
+template <int LPE> __device__ __forceinline__ unsigned row_min_u(unsigned x)
+{
+    x = min(x, (unsigned)dpp_i<DPP_XOR1>((int)x));
+    x = min(x, (unsigned)dpp_i<DPP_XOR2>((int)x));
+    if (LPE >= 8) x = min(x, (unsigned)dpp_i<DPP_HMIRROR>((int)x));
+    if (LPE == 16) x = min(x, (unsigned)dpp_i<DPP_MIRROR>((int)x));
+    return x;
+}
 template <int LPE, bool MAX> __device__ __forceinline__ float row_minmax_f(float x)
 {
     x = dpp_minmax_f<DPP_XOR1, MAX>(x);
@@ -738,9 +757,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     using G = Geo<Q, LPE>;
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
     // ---- A ----
-    float lmin = mvc[0];
-#pragma unroll
-    for (int e = 1; e < G::EPL; ++e) lmin = vminf(mvc[e], lmin);
+    const float lmin = array_min_f(mvc);
     const float rmin = row_minmax_f<LPE, false>(lmin);
     float T = __builtin_inff();
     int cnt = Q;
@@ -1004,15 +1021,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     if (rowact) store_row<Q, LPE>(app_row, rl, napp);
 
     // ---- Decision (tools.c:312-330) of this variable node; the later visit of the sweep wins ----
-    float lv = EMS_SENTINEL;
-    int lg = 0x7FFFFFFF;
+    //      first strict minimum below 1e5 = the row minimum, at the lowest symbol that attains it
+    const float lv = row_minmax_f<LPE, false>(array_min_f(napp));
+    unsigned lgu = 0x7FFFFFFFu;
 #pragma unroll
-    for (int e = 0; e < G::EPL; ++e) {
-        const bool lt = napp[e] < lv;
-        lv = lt ? napp[e] : lv;
-        lg = lt ? G::sym_of(e, rl) : lg;
-    }
-    row_argmin<LPE>(lv, lg);
+    for (int e = G::EPL - 1; e >= 0; --e) lgu = (napp[e] == lv) ? (unsigned)G::sym_of(e, rl) : lgu;   // a lane's symbols ascend with e
+    const int lg = (int)row_min_u<LPE>(lgu);
     if (rowact && rl == 0) P.decide[(size_t)f * P.N + vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
     wave_lds_sync();
     STAMP(3);
