@@ -891,7 +891,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 template <int Q, int LPE>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                           EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int lane
+                                           EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -993,7 +993,6 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
-    const int oid = P.out_list[t];
     const EmsEntry *ol = lists + oid * nmp;
     const int stp = (C.dc == 2) ? nm : lens[oid];
     const float dflt = ol[stp - 1].v + C.offset;
@@ -1086,6 +1085,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
     const int trow = row < C.dc ? row : C.dc - 1;
+    const int oid = P.out_list[trow];     // list holding this row's output (read once: a kernel-argument load)
 
     uint8_t *wbase = smem + wg_header_bytes(Q, P.M) + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
