@@ -905,8 +905,9 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     const int nm = C.nm;
     const int qm1 = Q - 1;
     const int edge = cn * C.dc + t;
-    float *app_row = P.app + ((size_t)f * P.N + vn) * Q;
-    uint8_t *rec = P.ctov + ((size_t)f * P.E + edge) * P.rec_bytes;
+    // frame bases are wave-uniform (scalar registers); the per-lane part is a 32-bit offset
+    float *app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
+    uint8_t *rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
     float *drow = dense + row * Q;
 
     // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279).
@@ -1026,7 +1027,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 #pragma unroll
     for (int e = G::EPL - 1; e >= 0; --e) lgu = (napp[e] == lv) ? (unsigned)G::sym_of(e, rl) : lgu;   // a lane's symbols ascend with e
     const int lg = (int)row_min_u<LPE>(lgu);
-    if (rowact && rl == 0) P.decide[(size_t)f * P.N + vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
+    if (rowact && rl == 0) (P.decide + (size_t)f * P.N)[(unsigned)vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
     wave_lds_sync();
     STAMP(3);
 }
