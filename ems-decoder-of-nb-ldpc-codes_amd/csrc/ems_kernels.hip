@@ -750,12 +750,34 @@ template <int LPE> __device__ __forceinline__ int row_excl_scan_i(int x, int rl)
     return inc - x;
 }
 
+// bit e of the result is set iff x[e] > T, read off the sign of the packed difference T - x[e] (T must not be -0,
+// no NaNs): two elements per subtraction, one v_alignbit per element, no VCC traffic.
+template <int N> __device__ __forceinline__ unsigned above_mask(const float (&x)[N], float T)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    static_assert(N % 2 == 0, "pairs");
+    const v2f t2 = {T, T};
+    unsigned a = 0u;
+#pragma unroll
+    for (int e = N - 2; e >= 0; e -= 2) {          // descending: element e ends up on bit e
+        const v2f d = t2 - v2f{x[e], x[e + 1]};
+        a = __builtin_amdgcn_alignbit(a, __float_as_uint(d.y), 31);
+        a = __builtin_amdgcn_alignbit(a, __float_as_uint(d.x), 31);
+    }
+    return a;
+}
+
 template <int Q, int LPE>
 __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
-                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big, float hint, float &T_out)
+                                                 int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big, float hint, float &T_out,
+                                                 float *drow)
 {
     using G = Geo<Q, LPE>;
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
+    // wide rows: the survivors of a threshold are kept as a per-lane bit mask (above_mask) and compacted by walking
+    // the set bits -- a lane owns EPL symbols but only one or two survive
+    constexpr bool BYMASK = (G::EPL >= 4) && (Q > SEL_CAP);
+    unsigned am = 0u;
     // ---- A ----
     const float lmin = array_min_f(mvc);
     const float rmin = row_minmax_f<LPE, false>(lmin);
@@ -769,12 +791,17 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         int clo = 1, chi = 0;
         bool hiv = false;
         const bool hinted = hint > rmin && hint < 3.0e38f;             // previous sweep's threshold of this edge
-        T = hinted ? hint : rmaxl;
+        T = (hinted ? hint : rmaxl) + 0.0f;      // (+0.0f: never -0, see above_mask)
         done = false;
         for (int it = 0; it < 12; ++it) {
             int c = 0;
+            if (BYMASK) {
+                if constexpr (G::EPL % 2 == 0) am = above_mask(mvc, T);
+                c = G::EPL - __popc(am);
+            } else {
 #pragma unroll
-            for (int e = 0; e < G::EPL; ++e) c += (mvc[e] <= T) ? 1 : 0;
+                for (int e = 0; e < G::EPL; ++e) c += (mvc[e] <= T) ? 1 : 0;
+            }
             lc = c;                          // (a finished row keeps its T, so the recount is the same number)
             c = row_sum_i<LPE>(c);
             if (!done) {
@@ -793,7 +820,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                         if (!(nt > lo && nt < hi)) nt = lo + (hi - lo) * 0.5f;
                         if (!(nt > lo && nt < hi)) nt = hi;                // no float in between: give up below
                     }
-                    T = nt;
+                    T = nt + 0.0f;
                 }
             }
             DBG_ADD(1, 1);
@@ -814,13 +841,33 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     lds_f32 *svals = (lds_f32 *)(uintptr_t)srow;
     lds_u32 *ssyms = (lds_u32 *)(uintptr_t)srow + (SEL_CAP + LPE);
     int off = row_excl_scan_i<LPE>(lc, rl);
+    if (BYMASK) {
+        // park the row in its (now free) staging row so that a lane can fetch the element a mask bit names
+        store_row<Q, LPE>(drow, rl, mvc);
+        unsigned dbase = (unsigned)(uintptr_t)(lds_f32 *)drow;
+        asm volatile("" : "+v"(dbase));
+        const lds_f32 *dl = (const lds_f32 *)(uintptr_t)dbase;
+        unsigned S = ~am & ((1u << (G::EPL & 31)) - 1u);
+        wave_lds_sync();
+        while (__ballot(S != 0u) != 0ull) {
+            if (S != 0u) {
+                const int e = __ffs(S) - 1;
+                S &= S - 1u;
+                const unsigned sym = (unsigned)(((e & ~(G::VW - 1)) * LPE) + rl * G::VW + (e & (G::VW - 1)));   // Geo::sym_of
+                svals[off] = dl[sym];
+                ssyms[off] = sym;
+                ++off;
+            }
+        }
+    } else {
 #pragma unroll
-    for (int e = 0; e < G::EPL; ++e) {
-        const bool sv = mvc[e] <= T;
-        const int slot = sv ? off : SEL_CAP + rl;                       // non-survivors land in this lane's dummy slot
-        svals[slot] = mvc[e];
-        ssyms[slot] = (unsigned)G::sym_of(e, rl);
-        off += sv ? 1 : 0;
+        for (int e = 0; e < G::EPL; ++e) {
+            const bool sv = mvc[e] <= T;
+            const int slot = sv ? off : SEL_CAP + rl;                   // non-survivors land in this lane's dummy slot
+            svals[slot] = mvc[e];
+            ssyms[slot] = (unsigned)G::sym_of(e, rl);
+            off += sv ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {                                     // slots cnt..SEL_CAP-1 never count as smaller
@@ -952,7 +999,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
     if (false)
 #endif
-    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
