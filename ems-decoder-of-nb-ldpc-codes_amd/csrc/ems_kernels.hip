@@ -73,6 +73,12 @@ __device__ __forceinline__ int red8_mini(int x)
     x = min(x, dpp_i<DPP_HMIRROR>(x));
     return x;
 }
+__device__ __forceinline__ int red16_mini(int x)
+{
+    x = red8_mini(x);
+    x = min(x, dpp_i<DPP_MIRROR>(x));
+    return x;
+}
 __device__ __forceinline__ unsigned red8_or(unsigned x)
 {
     x |= (unsigned)dpp_i<DPP_XOR1>((int)x);
@@ -227,11 +233,12 @@ __device__ __forceinline__ unsigned red8_minu(unsigned x)
 
 // Register-light form of es_post for the rare continuation (T up to 64 picks): same algorithm, the
 // per-pick value/symbol are recomputed in each of the three passes instead of being kept in registers.
+// (p, gbase: lane within / first lane of the task's 16 lanes.)
 __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
                                            const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
                                            int nbOper, int &S_out)
 {
-    const int NJ = (T + 7) >> 3;
+    const int NJ = (T + 15) >> 4;
     auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &k) {
         const unsigned pk = picks[ok ? i : 0];
         const int w = pk >> 5;
@@ -244,19 +251,19 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     wave_lds_sync();
     int lim = 1 << 20;
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         const bool ok = has && i < T;
         float v; unsigned sy; int k;
         gather(i, ok, v, sy, k);
         const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
         lim = min(lim, li);
     }
-    lim = red8_mini(lim);
+    lim = red16_mini(lim);
     const bool stopped = lim <= T;
     lim = min(lim, T);
     wave_lds_sync();
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         if (has && i < lim) atomicMax(&tbl[sy & 0xFFu], (unsigned)(ES_MAX_STEPS - i));
@@ -264,18 +271,18 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     wave_lds_sync();
     int base = 0;
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         const bool u = has && i < lim && tbl[sy & 0xFFu] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{v, sy & 0xFFu};
         base += __popc(m8);
     }
     wave_lds_sync();
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         if (has && i < lim) tbl[sy & 0xFFu] = 0u;
@@ -355,14 +362,15 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
 #endif
 }
 
-// Post-pass of the first T picks of a stage (T <= 8 NJ): stop rules, first-occurrence dedupe through the
+// Post-pass of the first T picks of a stage by the 16 lanes of its task (T <= 16 NJ; p, gbase: lane within / first
+// lane of the 16; p8, gbase8: the same for the 8-lane merge group): stop rules, first-occurrence dedupe through the
 // symbol table, ordered compaction into `out`.  When some group has neither nm outputs nor a stop yet (about
 // one stage in ten at nm = 20: duplicates eat picks), the merge runs 8 more steps with the exact rule and the
 // new picks go through the same table incrementally -- its first-pass claims are still in place, and a later
 // pick never displaces an earlier one (ds_max of ES_MAX_STEPS - i).  tbl is all-zero on entry and on exit.
 template <int NJ>
 __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
-                                        uint8_t *picks, uint8_t *dummy, int q, int p, int gbase, bool has, int T, int nm,
+                                        uint8_t *picks, uint8_t *dummy, int q, int p, int gbase, int p8, int gbase8, bool has, int T, int nm,
                                         int nbOper, int &S_out, unsigned &hv, int &y, float fxv, const EmsEntry *mvy, int &T_done)
 {
     wave_lds_sync();
@@ -381,27 +389,27 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     };
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         int li;
         gather(i, has && i < T, val[j], sym[j], li);
         lim = min(lim, li);
     }
-    lim = red8_mini(lim);
+    lim = red16_mini(lim);
     bool stopped = lim <= T;
     lim = min(lim, T);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         if (has && i < lim) atomicMax(&tbl[sym[j]], (unsigned)(ES_MAX_STEPS - i));
     }
     wave_lds_sync();
     int base = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 8 * j;
+        const int i = p + 16 * j;
         const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
         base += __popc(m8);
@@ -413,22 +421,22 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     if (__ballot(has && !done) != 0ull) {
         DBG_ADD(4, 1);
         const int T2 = min(T + 8, nbOper);
-        es_merge<true>(hv, y, fxv, mvy, picks, dummy, p, gbase, T, T2);
+        es_merge<true>(hv, y, fxv, mvy, picks, dummy, p8, gbase8, T, T2);
         T_done = T2;
         wave_lds_sync();
         const int i = T + p;
-        const bool ok = has && !done && i < T2;
+        const bool ok = has && !done && p < 8 && i < T2;
         float v;
         int li;
         gather(i, ok, v, symx, li);
-        int lim2 = red8_mini(li);
+        int lim2 = red16_mini(li);
         const bool stopped2 = lim2 <= T2;
         lim2 = min(lim2, T2);
         clrx = ok && i < lim2;
         if (clrx) atomicMax(&tbl[symx], (unsigned)(ES_MAX_STEPS - i));
         wave_lds_sync();
         const bool u = clrx && tbl[symx] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{v, symx};
         if (!done) {
@@ -439,7 +447,7 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-        if (has && p + 8 * j < lim) tbl[sym[j]] = 0u;
+        if (has && p + 16 * j < lim) tbl[sym[j]] = 0u;
     if (clrx) tbl[symx] = 0u;
     S_out = min(base, nm);
     return done;
@@ -448,9 +456,13 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
                                               int lane, uint2 task, int nm, int nbOper, int T1)
 {
-    const int p = lane & 7;
+    // A task owns 16 lanes.  The merge needs 8 (its 8 competitors): both halves run it identically (same inputs,
+    // same picks written to the same bytes); the post-pass then spreads the picks over all 16 lanes.
+    const int p = lane & 7;                         // competitor
     const int gbase = lane & ~7;
-    const int gsel = (lane >> 3) & 3;
+    const int p16 = lane & 15;                      // post-pass lane
+    const int gbase16 = lane & ~15;
+    const int gsel = lane >> 4;
     const bool has = (task.y >> 16) != 0u;          // see es_task(): byte offsets of the lists, output id + 1
     const int o_id = (int)(task.y >> 16) - 1;
     const int nmp = list_stride(nm);
@@ -459,12 +471,12 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (task.x >> 16));
     EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (task.y & 0xFFFFu));
     unsigned *tbl = tbl_base + gsel * q;
-    uint8_t *picks = picks_base + (lane >> 3) * (ES_MAX_STEPS + 4); // 8 areas 17 dwords apart (bank spread); lanes without a task scribble in theirs
+    uint8_t *picks = picks_base + gsel * (ES_MAX_STEPS + 4);            // pick areas 17 dwords apart (bank spread); lanes without a task scribble in theirs
     uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;  // one dword per lane: no same-dword byte writes
 
     if (has) {
-#pragma unroll 5
-        for (int k = p; k < nmp; k += 8) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
+#pragma unroll 3
+        for (int k = p16; k < nmp; k += 16) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
     }
 
     const bool rowc = p < 4;
@@ -490,16 +502,16 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
     int Td = T1;   // picks merged so far
-    if (T1 <= 16) done = es_post<2>(in1, in2, out, tbl, picks, dummy, q, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else if (T1 <= 24) done = es_post<3>(in1, in2, out, tbl, picks, dummy, q, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else done = es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, T1, nm, nbOper, S);
+    if (T1 <= 16) done = es_post<1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (T1 <= 32) done = es_post<2>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else done = es_post_rt(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
         // rare: neither nm outputs nor a stop within the first nm+3 (+8) picks -> merge on up to nbOper
         DBG_ADD(6, 1);
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
-        es_post_rt(in1, in2, out, tbl, picks, q, p, gbase, has, nbOper, nm, nbOper, S);
+        es_post_rt(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
     }
-    if (has && p == 0) lens[o_id] = S;
+    if (has && p16 == 0) lens[o_id] = S;
 }
 
 // Decoder parameters as the device functions see them.  In the specialised kernel instantiations
@@ -553,7 +565,7 @@ __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
                                         int lane, bool literal)
 {
-    const int grp = lane >> 3;
+    const int grp = lane >> 4;                      // 16 lanes per elementary-step task (the literal form uses 8 of them twice over)
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= C.nsteps; ++t) {
         const uint2 task = sched[(t - 1) * 8 + grp];
@@ -847,7 +859,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         unsigned dbase = (unsigned)(uintptr_t)(lds_f32 *)drow;
         asm volatile("" : "+v"(dbase));
         const lds_f32 *dl = (const lds_f32 *)(uintptr_t)dbase;
-        unsigned S = ~am & ((1u << (G::EPL & 31)) - 1u);
+        unsigned S = ~am & (G::EPL >= 32 ? 0xFFFFFFFFu : ((1u << (G::EPL & 31)) - 1u));
         wave_lds_sync();
         while (__ballot(S != 0u) != 0ull) {
             if (S != 0u) {
@@ -1375,7 +1387,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
         big = big || (!i1 && !(v1 >= 0.0f && v1 < 1e4f)) || (!i2 && !(v2 >= 0.0f && v2 < 1e4f));
     }
     wave_lds_sync();
-    const bool g0 = lane < 8;
+    const bool g0 = lane < 16;
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
     if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
         es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3));
