@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--workload", default="gf256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-operational", action="store_true",
+                    help="skip the side measurement with early exit enabled (SURVEY.md 8(d) 'operational' figure)")
     ap.add_argument("--synthetic-zero-codeword", action="store_true",
                     help="skip the host encoder: all-zero codeword + numpy AWGN (faster set-up, same work)")
     a = ap.parse_args()
@@ -173,6 +175,41 @@ def main():
         dt = float(t.item())
     tot = counters.cpu().tolist()
 
+    # ---- side figure (never `value`): early exit enabled at the operating point of SURVEY.md 8(d) ----
+    oper = None
+    OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}[a.workload]
+    if rank == 0 and world == 1 and not a.no_operational and not a.synthetic_zero_codeword:
+        nd = min(256, B)
+        with c_stdout_to_stderr():
+            src = harness.FrameSource(matrix, nm)
+            src.position(1 << 20)                   # frames far from the ones of the timed run
+            ocw, onoisy, osigma = src.draw(nd, OPER_EBN)
+            src.close()
+        Bo = 2 * B
+        reps = -(-Bo // nd)
+        ocw = np.tile(ocw, (reps, 1))[:Bo]; onoisy = np.tile(onoisy, (reps, 1, 1))[:Bo]
+        od = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bo, device=local, early_exit=True)
+        pkg._check(pkg.lib().ems_llr_init(od.h, pkg._ptr(onoisy), np.float32(osigma), Bo))
+        od.set_codewords(ocw)
+        od.synchronize()
+
+        def ostep():
+            od.llr_init_dev(od.noisy_dev_ptr, osigma, Bo)
+            od.decode(Bo)
+            nb = od.count_errors_resident(Bo)
+            it = np.zeros(Bo, np.int32); sy = np.zeros(Bo, np.int32)
+            pkg._check(pkg.lib().ems_get_results(od.h, Bo, None, pkg._ptr(it), pkg._ptr(sy)))
+            return nb, it
+
+        ostep()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            onb, oit = ostep()
+        odt = (time.perf_counter() - t1) / 2
+        oper = {"frames_per_s": round(Bo / odt, 1), "EbN0_dB": OPER_EBN, "batch": Bo, "distinct_frames": nd,
+                "avg_iterations": round(float(oit.mean()), 2), "frame_errors": int((onb != 0).sum()),
+                "note": "early exit on (NB_LDPC.c:470); reported beside, never instead of, the fixed-work value"}
+        od.close()
     if rank == 0:
         value = world * B * a.steps / dt
         sweeps = itmax - 1
@@ -197,6 +234,8 @@ def main():
                          "llr_init_avg_ms": round(float(np.mean(lms)), 3)},
             "host_setup_s": round(t_setup, 1),
         }
+        if oper is not None:
+            out["config"]["operational_early_exit"] = oper
         tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tr):
             try:
