@@ -333,33 +333,23 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
         const unsigned m = red8_minu(hv);
         bool iw = (hv == m);
         if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
-#ifndef EMS_NO_PREFETCH2
         const float nx = wprev ? x1 : x0;
-#else
-        const float nx = x0;
-#endif
         (iw ? pk : dummy)[ss] = (uint8_t)y;      // losers write to their own dummy dword (+ss: still one dword per lane)
         y += iw ? 1 : 0;
         asm("" : "+v"(y));                    // one add-with-carry per step (no re-association across steps)
         hv = iw ? (unsigned)__float_as_int(fxv + nx) : hv;
         lds_cf32 *qn = at(y);
         x0 = qn[2];
-#ifndef EMS_NO_PREFETCH2
         x1 = qn[4];
         wprev = iw;
-#endif
     };
     int ss = from;
 #pragma unroll
-#ifndef EMS_NO_PREFETCH2
     for (; ss + 1 < to; ss += 2) {
         step(a0, a1, ss);
         step(b0, b1, ss + 1);
     }
     if (ss < to) step(a0, a1, ss);
-#else
-    for (; ss < to; ++ss) step(a0, a1, ss);
-#endif
 }
 
 // Post-pass of the first T picks of a stage by the 16 lanes of its task (T <= 16 NJ; p, gbase: lane within / first
@@ -570,10 +560,6 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
     for (int t = 1; t <= C.nsteps; ++t) {
         const uint2 task = sched[(t - 1) * 8 + grp];
         if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
-#ifdef EMS_DUP_STAGE   /* timing experiment: every elementary-step stage twice (idempotent) */
-        wave_lds_sync();
-        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
-#endif
         else {
             const int lb = list_stride(C.nm) * 8;
             const bool has = (task.y >> 16) != 0u;
@@ -684,12 +670,6 @@ constexpr int SEL_CAP = 32;
 // over the LDS banks (row bases 8/20/10 dwords apart modulo 32 for 4/8/16 rows)
 __host__ __device__ constexpr int surv_stride(int lpe) { return SEL_CAP + lpe + (lpe == 16 ? 4 : (lpe == 8 ? 2 : 1)); }
 
-__device__ __forceinline__ unsigned mono_key(float v)
-{
-    const unsigned b = (unsigned)__float_as_int(v + 0.0f);     // -0 -> +0
-    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-}
-
 // IEEE min/max of two non-NaN floats in one instruction (fminf/fmaxf would add canonicalising v_max's; a
 // compare + select costs three issue slots with the VCC hazard).  Not volatile: the compiler may schedule it.
 __device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -731,16 +711,6 @@ template <int LPE, bool MAX> __device__ __forceinline__ float row_minmax_f(float
     x = dpp_minmax_f<DPP_XOR2, MAX>(x);
     if (LPE >= 8) x = dpp_minmax_f<DPP_HMIRROR, MAX>(x);
     if (LPE == 16) x = dpp_minmax_f<DPP_MIRROR, MAX>(x);
-    return x;
-}
-
-template <int LPE, typename F> __device__ __forceinline__ float row_reduce_f(float x, F better)
-{
-    float o;
-    o = dpp_f<DPP_XOR1>(x); x = better(o, x) ? o : x;
-    o = dpp_f<DPP_XOR2>(x); x = better(o, x) ? o : x;
-    if (LPE >= 8) { o = dpp_f<DPP_HMIRROR>(x); x = better(o, x) ? o : x; }
-    if (LPE == 16) { o = dpp_f<DPP_MIRROR>(x); x = better(o, x) ? o : x; }
     return x;
 }
 template <int LPE> __device__ __forceinline__ int row_sum_i(int x)
@@ -1007,10 +977,6 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     EmsEntry *inl = lists + t * nmp;
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
     float T_sel = __builtin_inff();
-#ifdef EMS_ABLATE_SEL
-    for (int k = rl; k < nm; k += LPE) inl[k] = EmsEntry{mvc[k % G::EPL] * 0.0f + (float)k, (unsigned)(k + lh) & 0xFFu};  // timing-only
-    if (false)
-#endif
     if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
@@ -1038,17 +1004,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 
     STAMP(1);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
-#ifndef EMS_ABLATE_ES
     // the dense staging rows are dead until the expansion below: their first 4Q words serve as the four dedupe
     // tables of the elementary steps, zeroed here and kept all-zero from stage to stage
     unsigned *tbl = reinterpret_cast<unsigned *>(dense);
     for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
     wave_lds_sync();
     cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
-#else
-    if (lane < 16) lens[lane < C.n_lists ? lane : 0] = nm;   // timing-only build: wrong results
-    wave_lds_sync();
-#endif
 
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
@@ -1122,10 +1083,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
     C.dc = DC > 0 ? DC : P.dc;
     C.nm = NM > 0 ? NM : P.nm;
     C.nbOper = P.nbOper;
-#ifndef EMS_T1_EXTRA
-#define EMS_T1_EXTRA 3
-#endif
-    C.T1 = NM > 0 ? NM + EMS_T1_EXTRA : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
+    C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
     C.q = Q;
     C.nsteps = C.dc - 2;
     C.n_lists = C.dc + 3 * (C.dc - 2);
