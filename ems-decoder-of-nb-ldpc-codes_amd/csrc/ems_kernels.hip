@@ -208,14 +208,15 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
 // ------------------------------------------------------------------------------------------------
 // ElementaryStep, fast form.  The bubble loop of bubble_decoder.c:472-562 is a stable 8-way merge whose
 // pick sequence does not depend on the output bookkeeping, so it is split in two:
-//   1. the serial loop only merges: per step one 8-lane min, the lowest competitor among the ties,
-//      the winner records (competitor, position) as one byte and advances -- ~25 instructions;
-//   2. a parallel post-pass over the T recorded picks recomputes value + symbol of every pick, finds
-//      the first stop (invalid source index -> before the pick, bubble_decoder.c:478; last row/column
-//      -> after it, :506), removes symbols already emitted (first occurrence wins, :490; one
-//      ds_max per pick on a q-entry LDS table) and compacts the survivors in order, cutting at nm (:502).
-// The loop first runs nm+3 steps (the reference needs 20.3 on average at nm = 20); only if some group
-// has neither nm outputs nor a stop by then does it continue to nbOper and repeat the post-pass.
+//   1. the serial loop only merges: per step one 8-lane min, the winner records (competitor, position)
+//      as one byte and advances -- 10 VALU + 2 LDS instructions (es_merge);
+//   2. a parallel post-pass over the T recorded picks (16 lanes per task, es_post) recomputes value +
+//      symbol of every pick, finds the first stop (invalid source index -> before the pick,
+//      bubble_decoder.c:478; last row/column -> after it, :506), removes symbols already emitted (first
+//      occurrence wins, :490; one ds_max per pick on a q-entry LDS table) and compacts the survivors in
+//      order, cutting at nm (:502).
+// The loop first runs nm+3 steps (the reference needs 20.3 on average at nm = 20); a task with neither nm
+// outputs nor a stop by then gets 8 more steps, post-processed incrementally, and only then the full nbOper.
 // Values inside the check node are non-negative floats (normalised inputs and their sums), so the
 // IEEE order equals the unsigned order of the bit patterns; the loop compares bit patterns.
 // ------------------------------------------------------------------------------------------------
