@@ -5,7 +5,8 @@
  * frame, never reseeded), same progress line, same 40-erroneous-frame stop and same result-file line as
  * the reference's main() (NB_LDPC.c:63-604).  The only structural change is the one north_star asks
  * for: the inline per-frame decode block (NB_LDPC.c:266-472) is replaced by one batched call into the
- * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH), decoded
+ * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH) by EMS_THREADS host
+ * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
  *
  *   ems_sim NbMonteCarlo NbIterMax FileMatrix EbN NbMax Offset NbOper
@@ -15,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "ems_abi.h"
 #include "nbldpc_ref_api.h"
@@ -48,6 +50,9 @@ int main(int argc, char *argv[])
     int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 64;
     if (batch < 1) batch = 1;
     const int device = getenv("EMS_DEVICE") ? atoi(getenv("EMS_DEVICE")) : 0;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int threads = getenv("EMS_THREADS") ? atoi(getenv("EMS_THREADS")) : (int)(ncpu > 16 ? 16 : (ncpu < 1 ? 1 : ncpu));
+    if (threads < 1) threads = 1;
     int Idum = -1;
 
     printf(" Monte-Carlo simulation of Non-Binary LDPC decoder \n\n");
@@ -98,15 +103,23 @@ int main(int argc, char *argv[])
     int *iters = malloc(sizeof(int) * batch), *synd = malloc(sizeof(int) * batch), *nberr = malloc(sizeof(int) * batch);
 
     int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
-    double t_decode = 0;
+    double t_decode = 0, t_gen = 0;
     while (nb < NbMonteCarlo && !stop) {
         const int B = (NbMonteCarlo - nb) < batch ? (NbMonteCarlo - nb) : batch;
         float sigma = 0;
-        for (int b = 0; b < B; b++) {                                   /* NB_LDPC.c:255-261 draw order */
-            RandomBinaryGenerator(N, code.M, code.GF, logGF, KBIN, KSYMB, table.BINGF, &Idum);
-            Encoding(&code, &table, cw + (size_t)b * N, NBIN, KSYMB);
-            sigma = ems_awgn_bpsk_noise(&code, NBIN, EbN, &Idum, noisy + (size_t)b * N * logGF);
+        struct timespec g0, g1;
+        clock_gettime(CLOCK_MONOTONIC, &g0);
+        if (threads > 1) {                                              /* same bits, frame-parallel (nbldpc_ref_api.h) */
+            if (ems_draw_frames(&code, &table, nb, B, EbN, threads, cw, noisy, &sigma)) die("ems_draw_frames", -1);
+        } else {
+            for (int b = 0; b < B; b++) {                               /* NB_LDPC.c:255-261 draw order */
+                RandomBinaryGenerator(N, code.M, code.GF, logGF, KBIN, KSYMB, table.BINGF, &Idum);
+                Encoding(&code, &table, cw + (size_t)b * N, NBIN, KSYMB);
+                sigma = ems_awgn_bpsk_noise(&code, NBIN, EbN, &Idum, noisy + (size_t)b * N * logGF);
+            }
         }
+        clock_gettime(CLOCK_MONOTONIC, &g1);
+        t_gen += (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         if ((rc = ems_decode_batch(h, noisy, sigma, B, decide, iters, synd))) die("ems_decode_batch", rc);
@@ -145,8 +158,8 @@ int main(int argc, char *argv[])
     printf(" \n results printed \n ");
     printf("\n");
     printf("Simulation complete at time: %s", ts);
-    fprintf(stderr, "[ems_sim] %d frames, GPU decode wall %.3f s (%.1f frames/s incl. PCIe), batch %d\n", nb, t_decode,
-            t_decode > 0 ? nb / t_decode : 0.0, batch);
+    fprintf(stderr, "[ems_sim] %d frames, GPU decode wall %.3f s (%.1f frames/s incl. PCIe), batch %d; host frame generation %.3f s on %d thread(s)\n",
+            nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, t_gen, threads);
 
     ems_destroy(h);
     free(col); free(coef); free(cw); free(noisy); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);

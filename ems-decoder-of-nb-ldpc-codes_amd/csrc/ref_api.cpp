@@ -9,6 +9,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ems_abi.h"
@@ -323,6 +324,104 @@ float ems_awgn_bpsk_noise(code_t *code, int **NBIN, float EbN, int *init_rand, f
             noisy[(size_t)n * code->logGF + l] = (float)((double)(1 - 2 * NBIN[n][l]) + (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * PI * (double)v));
         }
     return sigma;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame generation for the batched harness: frames [first_frame, first_frame + count) of the reference's
+// drand48 stream (X0 = 0, never reseeded), i.e. exactly what RandomBinaryGenerator + Encoding +
+// ModelChannel_AWGN_BPSK's noise draw would have produced frame after frame (NB_LDPC.c:255-261), but
+// generated by `threads` host threads at once: every frame owns draws [f*dpf, (f+1)*dpf) of the stream
+// (dpf = K*logGF + 2*N*logGF) and the LCG X <- a*X + c mod 2^48 can be positioned anywhere in O(log n).
+// Each thread takes a contiguous chunk of frames and runs the back-substitution of Encoding (tools.c:232)
+// for the whole chunk in one pass over matUT (the 131 MB of cfg 4 are streamed once per chunk, not per frame).
+// libc's drand48 state is neither used nor advanced.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Lcg48 {
+    static constexpr uint64_t A = 0x5DEECE66DULL, C = 0xBULL, MASK = (1ULL << 48) - 1;
+    uint64_t x;
+    static uint64_t jump(uint64_t x0, uint64_t n)       // state after n draws from x0
+    {
+        uint64_t a = 1, c = 0, ba = A, bc = C;
+        while (n) {
+            if (n & 1) { a = (ba * a) & MASK; c = (ba * c + bc) & MASK; }
+            bc = (ba * bc + bc) & MASK;
+            ba = (ba * ba) & MASK;
+            n >>= 1;
+        }
+        return (a * x0 + c) & MASK;
+    }
+    float next()                                          // (float)drand48(), tools.c:71-73
+    {
+        x = (A * x + C) & MASK;
+        return (float)ldexp((double)x, -48);
+    }
+};
+} // namespace
+
+int ems_draw_frames(code_t *code, table_t *table, long first_frame, int count, float EbN, int threads, int *codewords,
+                    float *noisy, float *sigma_out)
+{
+    if (!code || !table || !code->matUT || !code->Perm || count < 0 || first_frame < 0 || !codewords || !noisy) return -1;
+    const int N = code->N, M = code->M, K = N - M, GF = code->GF, logGF = code->logGF;
+    const uint64_t dpf = (uint64_t)K * logGF + 2ULL * N * logGF;
+    const float sigma = (float)sqrt(1.0 / (2.0 * (double)code->rate * pow(10.0, (double)EbN / 10.0)));   /* channel.c:51 */
+    if (sigma_out) *sigma_out = sigma;
+    if (count == 0) return 0;
+    std::vector<int> i2b(GF), b2i(GF);                     // binary image <-> symbol index (ADDGF = XOR of images, init.c:37)
+    for (int g = 0; g < GF; ++g) {
+        int x = 0;
+        for (int l = 0; l < logGF; ++l) x |= table->BINGF[g][l] << l;
+        i2b[g] = x; b2i[x] = g;
+    }
+    if (threads < 1) threads = 1;
+    threads = std::min(threads, count);
+    const int chunk = (count + threads - 1) / threads;
+    auto work = [&](int c0, int c1) {
+        const int C = c1 - c0;
+        const double PI = 3.1415926536;                    /* channel.c:18 */
+        std::vector<uint8_t> sym((size_t)N * C);           // [n][frame in chunk]
+        std::vector<Lcg48> rng(C);
+        std::vector<int> bits(logGF);
+        for (int fi = 0; fi < C; ++fi) {                   // RandomBinaryGenerator (tools.c:124)
+            rng[fi].x = Lcg48::jump(0, (uint64_t)(first_frame + c0 + fi) * dpf);
+            for (int k = 0; k < K; ++k) {
+                for (int l = 0; l < logGF; ++l) bits[l] = (int)floor(rng[fi].next() * 1.9999);
+                sym[(size_t)(M + k) * C + fi] = (uint8_t)Bin2GF(bits.data(), GF, logGF, table->BINGF);
+            }
+        }
+        std::vector<int> acc(C);
+        for (int m = M - 1; m >= 0; --m) {                 // Encoding (tools.c:232), all frames of the chunk per row
+            const int *row = code->matUT[m];
+            std::fill(acc.begin(), acc.end(), 0);
+            for (int n = m + 1; n < N; ++n) {
+                const int r = row[n];
+                if (!r) continue;
+                const int *mul = table->MULGF[r];
+                const uint8_t *sn = &sym[(size_t)n * C];
+                for (int fi = 0; fi < C; ++fi) acc[fi] ^= i2b[mul[sn[fi]]];
+            }
+            const int piv = row[m];
+            for (int fi = 0; fi < C; ++fi) sym[(size_t)m * C + fi] = (uint8_t)table->DIVGF[b2i[acc[fi]]][piv];
+        }
+        for (int fi = 0; fi < C; ++fi) {
+            int *cw = codewords + (size_t)(c0 + fi) * N;
+            float *ny = noisy + (size_t)(c0 + fi) * N * logGF;
+            for (int n = 0; n < N; ++n) cw[code->Perm[n]] = sym[(size_t)n * C + fi];
+            for (int n = 0; n < N; ++n)                    // noise draw of ModelChannel_AWGN_BPSK (channel.c:52-62)
+                for (int l = 0; l < logGF; ++l) {
+                    const float u = rng[fi].next();
+                    const float v = rng[fi].next();
+                    const int bit = table->BINGF[cw[n]][l];
+                    ny[(size_t)n * logGF + l] = (float)((double)(1 - 2 * bit) + (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * PI * (double)v));
+                }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int c0 = chunk; c0 < count; c0 += chunk) pool.emplace_back(work, c0, std::min(count, c0 + chunk));
+    work(0, std::min(count, chunk));
+    for (auto &t : pool) t.join();
+    return 0;
 }
 
 void ModelChannel_AWGN_BPSK(code_t *code, decoder_t *decoder, table_t *table, int **NBIN, float EbN, int *init_rand)

@@ -14,6 +14,9 @@ Mirrors the reference's main() loop (NB_LDPC.c:250-507) for N processes, one per
 Collectives go through torch.distributed (backend "nccl" == RCCL over xGMI on the GPU node, "gloo" in
 the CPU tests); without an initialised process group everything degenerates to one rank.
 """
+import ctypes as C
+import os
+
 import numpy as np
 
 from . import Code, Decoder
@@ -49,22 +52,43 @@ def batch_of_rank(round_idx, rank, world, batch, n_frames):
 
 
 class FrameSource:
-    """Draws frames exactly as the reference harness does, from any starting frame index."""
+    """Draws frames exactly as the reference harness does, from any starting frame index.
 
-    def __init__(self, matrix, nbMax):
+    `threads` > 1 (default: the host's cores, at most 16) generates a batch with the library's
+    `ems_draw_frames` (frame-parallel, LCG jump-ahead per frame, include/nbldpc_ref_api.h); `threads=1`
+    replays the reference's own call sequence on libc's drand48.  Both give the same bits
+    (tests/test_multi_rank_cpu.py)."""
+
+    def __init__(self, matrix, nbMax, threads=None):
         self.s = RefSession(matrix, nbMax, need_encoder=True)
         self.dpf = draws_per_frame(self.s.K, self.s.N, self.s.logGF)
+        self.threads = max(1, min(os.cpu_count() or 1, 16)) if threads is None else int(threads)
+        self.next_frame = 0
 
     def position(self, frame0):
+        self.next_frame = int(frame0)
         seed48(lcg_jump(0, frame0 * self.dpf))
 
     def draw(self, count, EbN):
         cws = np.zeros((count, self.s.N), np.int32)
         noisy = np.zeros((count, self.s.N, self.s.logGF), np.float32)
         sigma = 0.0
+        if self.threads > 1 and count > 0:
+            sg = C.c_float(0.0)
+            L = self.s.L
+            L.ems_draw_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_float)]
+            rc = L.ems_draw_frames(C.byref(self.s.code), C.byref(self.s.table), self.next_frame, count, C.c_float(EbN),
+                                   self.threads, cws.ctypes.data_as(C.c_void_p), noisy.ctypes.data_as(C.c_void_p), C.byref(sg))
+            if rc != 0:
+                raise RuntimeError("ems_draw_frames failed (%d)" % rc)
+            sigma = float(sg.value)
+            self.position(self.next_frame + count)      # keep libc's stream where the serial path would be
+            return cws, noisy, sigma
         for b in range(count):
             cws[b] = self.s.draw_codeword()
             sigma, noisy[b] = self.s.noise(EbN)
+        self.next_frame += count
         return cws, noisy, sigma
 
     def close(self):

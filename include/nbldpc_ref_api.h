@@ -107,6 +107,13 @@ int Decoding(code_t *code, table_t *table, decoder_t *decoder, int NbIterMax, in
 /* ---- NEW helper for batched harnesses: channel.c:51-62 only (sigma + BPSK + Box-Muller noise from
  *      drand48), observations written to noisy[N][logGF]; returns sigma. ---- */
 float ems_awgn_bpsk_noise(code_t *code, int **NBIN, float EbN, int *init_rand, float *noisy);
+/* NEW (batched harness): frames [first_frame, first_frame+count) (0-based) of the reference's drand48 stream --
+ * the codewords RandomBinaryGenerator + Encoding (tools.c:124, :232) and the samples the noise draw of
+ * ModelChannel_AWGN_BPSK (channel.c:51-62) would have produced frame after frame from X0 = 0 -- generated by
+ * `threads` host threads (LCG jump-ahead; libc's drand48 state is not touched).  codewords[count][N],
+ * noisy[count][N][logGF]; needs code->matUT/Perm (GaussianElimination).  Returns 0, or -1 on bad arguments. */
+int ems_draw_frames(code_t *code, table_t *table, long first_frame, int count, float EbN, int threads,
+                    int *codewords, float *noisy, float *sigma_out);
 
 #ifdef __cplusplus
 }

@@ -158,6 +158,27 @@ def test_frame_source_random_access(harness, orc):
     src.close()
 
 
+@pytest.mark.parametrize("mat,nm,count,threads,first", [("N96_K48_GF64", 16, 7, 3, 11), ("Mat24_N192_M96", 24, 5, 8, 0),
+                                                        ("Ahmed_64800_R34_GF16", 8, 3, 2, 2), ("Ahmed_64800_R12_GF256", 20, 3, 3, 1)])
+def test_threaded_frame_generation_equals_reference_call_sequence(harness, mat, nm, count, threads, first):
+    """ems_draw_frames (frame-parallel, own LCG with jump-ahead, chunked back-substitution) against the
+    reference's own call sequence RandomBinaryGenerator -> Encoding -> noise draw on libc's drand48."""
+    path = os.path.join(MAT, mat)
+    par = harness.FrameSource(path, nm, threads=threads)
+    par.position(first)
+    cw_p, ny_p, sg_p = par.draw(count, 1.5)
+    par.position(first)
+    par.threads = 1
+    cw_s, ny_s, sg_s = par.draw(count, 1.5)
+    assert sg_p == sg_s and (cw_p == cw_s).all() and ny_p.tobytes() == ny_s.tobytes()
+    cw_n, ny_n, _ = par.draw(1, 1.5)                    # the stream continues where the batch ended ...
+    par.threads = threads
+    par.position(first + count)
+    cw_m, ny_m, _ = par.draw(1, 1.5)                    # ... for either path
+    assert (cw_n == cw_m).all() and ny_n.tobytes() == ny_m.tobytes()
+    par.close()
+
+
 def test_compute_entry_points_fail_loudly_without_gpu(pkg):
     """No CPU fallback: on a box without a HIP device every compute call reports EMS_ENODEV."""
     c = pkg.Code(os.path.join(MAT, "N96_K48_GF64"))
