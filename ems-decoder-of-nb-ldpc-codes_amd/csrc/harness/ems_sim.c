@@ -12,6 +12,7 @@
  *   ems_sim NbMonteCarlo NbIterMax FileMatrix EbN NbMax Offset NbOper
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +26,39 @@ static void die(const char *what, int rc)
 {
     fprintf(stderr, "\n%s failed (%d): %s\n", what, rc, ems_last_error());
     exit(EXIT_FAILURE);
+}
+
+/* One batch of frames, drawn on the host (the reference's stream, NB_LDPC.c:255-261) while the GPU decodes the
+ * previous one. */
+typedef struct {
+    code_t *code; table_t *table;
+    int first, B, threads;                  /* frames [first, first+B) of the stream */
+    float EbN, sigma;
+    int *cw; float *noisy;                  /* [B][N], [B][N][logGF] */
+    int **NBIN, **KBIN, *KSYMB, *Idum;      /* scratch of the serial (threads == 1) path */
+    double seconds;
+    int rc;
+} gen_job;
+
+static void *generate(void *arg)
+{
+    gen_job *j = (gen_job *)arg;
+    struct timespec g0, g1;
+    clock_gettime(CLOCK_MONOTONIC, &g0);
+    j->rc = 0;
+    if (j->threads > 1) {                   /* same bits, frame-parallel (nbldpc_ref_api.h) */
+        j->rc = ems_draw_frames(j->code, j->table, j->first, j->B, j->EbN, j->threads, j->cw, j->noisy, &j->sigma);
+    } else {
+        const int N = j->code->N, logGF = j->code->logGF;
+        for (int b = 0; b < j->B; b++) {    /* the reference's own call sequence on libc's drand48 */
+            RandomBinaryGenerator(N, j->code->M, j->code->GF, logGF, j->KBIN, j->KSYMB, j->table->BINGF, j->Idum);
+            Encoding(j->code, j->table, j->cw + (size_t)b * N, j->NBIN, j->KSYMB);
+            j->sigma = ems_awgn_bpsk_noise(j->code, j->NBIN, j->EbN, j->Idum, j->noisy + (size_t)b * N * logGF);
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &g1);
+    j->seconds = (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);
+    return NULL;
 }
 
 int main(int argc, char *argv[])
@@ -97,29 +131,37 @@ int main(int argc, char *argv[])
     for (int n = 0; n < N; n++) NBIN[n] = calloc(logGF, sizeof(int));
     for (int k = 0; k < K; k++) KBIN[k] = calloc(logGF, sizeof(int));
     int *KSYMB = calloc(K, sizeof(int));
-    int *cw = malloc(sizeof(int) * (size_t)batch * N);
-    float *noisy = malloc(sizeof(float) * (size_t)batch * N * logGF);
+    int *cwbuf[2] = {malloc(sizeof(int) * (size_t)batch * N), malloc(sizeof(int) * (size_t)batch * N)};
+    float *nybuf[2] = {malloc(sizeof(float) * (size_t)batch * N * logGF), malloc(sizeof(float) * (size_t)batch * N * logGF)};
     int *decide = malloc(sizeof(int) * (size_t)batch * N);
     int *iters = malloc(sizeof(int) * batch), *synd = malloc(sizeof(int) * batch), *nberr = malloc(sizeof(int) * batch);
 
     int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
     double t_decode = 0, t_gen = 0;
+    gen_job job[2];
+    for (int i = 0; i < 2; i++)
+        job[i] = (gen_job){&code, &table, 0, 0, threads, EbN, 0.0f, cwbuf[i], nybuf[i], NBIN, KBIN, KSYMB, &Idum, 0.0, 0};
+    pthread_t producer;
+    int cur = 0, drawn = 0;                                             /* frames handed to the generator so far */
+    job[0].first = 0;
+    job[0].B = NbMonteCarlo < batch ? NbMonteCarlo : batch;
+    drawn = job[0].B;
+    generate(&job[0]);
     while (nb < NbMonteCarlo && !stop) {
-        const int B = (NbMonteCarlo - nb) < batch ? (NbMonteCarlo - nb) : batch;
-        float sigma = 0;
-        struct timespec g0, g1;
-        clock_gettime(CLOCK_MONOTONIC, &g0);
-        if (threads > 1) {                                              /* same bits, frame-parallel (nbldpc_ref_api.h) */
-            if (ems_draw_frames(&code, &table, nb, B, EbN, threads, cw, noisy, &sigma)) die("ems_draw_frames", -1);
-        } else {
-            for (int b = 0; b < B; b++) {                               /* NB_LDPC.c:255-261 draw order */
-                RandomBinaryGenerator(N, code.M, code.GF, logGF, KBIN, KSYMB, table.BINGF, &Idum);
-                Encoding(&code, &table, cw + (size_t)b * N, NBIN, KSYMB);
-                sigma = ems_awgn_bpsk_noise(&code, NBIN, EbN, &Idum, noisy + (size_t)b * N * logGF);
-            }
+        const int B = job[cur].B;
+        if (job[cur].rc) die("ems_draw_frames", job[cur].rc);
+        const float sigma = job[cur].sigma;
+        int *cw = job[cur].cw;
+        float *noisy = job[cur].noisy;
+        t_gen += job[cur].seconds;
+        int have_next = 0;
+        if (drawn < NbMonteCarlo) {                                     /* draw the next batch while this one decodes */
+            job[cur ^ 1].first = drawn;
+            job[cur ^ 1].B = (NbMonteCarlo - drawn) < batch ? (NbMonteCarlo - drawn) : batch;
+            drawn += job[cur ^ 1].B;
+            have_next = pthread_create(&producer, NULL, generate, &job[cur ^ 1]) == 0;
+            if (!have_next) generate(&job[cur ^ 1]);
         }
-        clock_gettime(CLOCK_MONOTONIC, &g1);
-        t_gen += (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         if ((rc = ems_decode_batch(h, noisy, sigma, B, decide, iters, synd))) die("ems_decode_batch", rc);
@@ -140,6 +182,8 @@ int main(int argc, char *argv[])
             fflush(stdout);
             if (nbErroneousFrames == 40) { stop = 1; break; }
         }
+        if (have_next) pthread_join(producer, NULL);                    /* (dropped if the 40-error stop came first) */
+        cur ^= 1;
     }
     /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
     const int nb_logged = stop ? nb : nb + 1;
@@ -162,7 +206,7 @@ int main(int argc, char *argv[])
             nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, t_gen, threads);
 
     ems_destroy(h);
-    free(col); free(coef); free(cw); free(noisy); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
+    free(col); free(coef); free(cwbuf[0]); free(cwbuf[1]); free(nybuf[0]); free(nybuf[1]); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
     for (int n = 0; n < N; n++) free(NBIN[n]);
     for (int k = 0; k < K; k++) free(KBIN[k]);
     free(NBIN); free(KBIN);

@@ -154,12 +154,25 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     rounds = 0
     stop = False
     n_rounds = -(-NbMonteCarlo // (batch * world))
+
+    def draw_round(r):                                  # this rank's frames of round r (host work)
+        start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
+        if count <= 0:
+            return None
+        src.position(start)
+        return src.draw(count, EbN)
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(1)                        # the next round is drawn while this one decodes
+    pending = pool.submit(draw_round, 0)
     for r in range(n_rounds):
         start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
         triples = np.full((batch, 3), -1, np.int64)
+        frames = pending.result()
+        if r + 1 < n_rounds:
+            pending = pool.submit(draw_round, r + 1)
         if count > 0:
-            src.position(start)
-            cws, noisy, sigma = src.draw(count, EbN)
+            cws, noisy, sigma = frames
             nberr, synd, iters = decode_fn(noisy, sigma, cws)
             triples[:count, 0], triples[:count, 1], triples[:count, 2] = nberr, synd, iters
         local = np.array([count, int((triples[:count, 0] != 0).sum()), int(triples[:count, 0].sum()),
@@ -188,9 +201,9 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
                     break
             if stop:
                 break
-        del round_err
         if stop:
             break
+    pool.shutdown(wait=True)                            # (a round drawn ahead of the stop is simply dropped)
     src.close()
     if dec is not None:
         dec.close()
