@@ -201,6 +201,30 @@ class Decoder:
         self.decode(B)
         return self.results(B)
 
+    # ---- v2 flavour (include/ems_abi.h: ems_v2_*) ----
+    def v2_load_likelihood(self, like, like_idx):
+        like = np.ascontiguousarray(like, np.float32)
+        like_idx = np.ascontiguousarray(like_idx, np.int32)
+        B = like.shape[0]
+        assert like.shape == (B, self.code.N, self.code.GF) and like_idx.shape == like.shape
+        _check(lib().ems_v2_load_likelihood(self.h, _ptr(like), _ptr(like_idx), B))
+        return B
+
+    def v2_decode(self, B):
+        _check(lib().ems_v2_decode(self.h, B))
+
+    def v2_decode_batch(self, like, like_idx):
+        B = self.v2_load_likelihood(like, like_idx)
+        self.v2_decode(B)
+        return self.results(B)
+
+    def v2_state(self, frame):
+        E, nm, N, q = self.code.desc.nbBranch, self.prm.nm, self.code.N, self.code.GF
+        st = dict(vtoc=np.zeros((E, nm), np.float32), vtoci=np.zeros((E, nm), np.int32), ctov=np.zeros((E, nm), np.float32),
+                  ctovi=np.zeros((E, nm), np.int32), app=np.zeros((N, q), np.float32))
+        _check(lib().ems_v2_get_state(self.h, frame, _ptr(st["vtoc"]), _ptr(st["vtoci"]), _ptr(st["ctov"]), _ptr(st["ctovi"]), _ptr(st["app"])))
+        return st
+
     def count_errors(self, codewords):
         cw = np.ascontiguousarray(codewords, np.int32)
         B = cw.shape[0]

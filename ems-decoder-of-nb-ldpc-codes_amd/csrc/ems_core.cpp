@@ -188,6 +188,13 @@ struct ems_handle {
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
     DevBuf<unsigned long long> d_stamps;
+    // v2 flavour (allocated on first ems_v2_load_likelihood)
+    std::vector<int> v2_t_dst, v2_vn_edge;
+    DevBuf<int> d_v2_t_dst, d_v2_vn_edge, d_v2_stage_idx, d_v2_bad;
+    DevBuf<float> d_v2_like, d_v2_vtoc, d_v2_ctov, d_v2_hint, d_v2_app, d_v2_stage_like;
+    DevBuf<uint8_t> d_v2_vtoci;
+    DevBuf<int16_t> d_v2_ctovi;
+    bool v2_ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_llr_ev = false, have_dec_ev = false;
@@ -340,7 +347,10 @@ void ems_destroy(ems_handle *h)
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
-    h->d_scratch.release(); h->d_stamps.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release();
+    h->d_scratch.release(); h->d_stamps.release();
+    h->d_v2_t_dst.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
+    h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
+    h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -628,6 +638,103 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf)
     return EMS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2 flavour (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c): same handle, own state.
+// ------------------------------------------------------------------------------------------------
+static int v2_prepare(ems_handle *h)
+{
+    if (h->v2_ready) return EMS_OK;
+    if (ems_lpe_for(h->dc) != 16) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 4 is not built", h->dc);
+    if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
+    // the reference's Flag trick (v2.c:2157) needs exactly two edges per variable node
+    std::vector<int> deg(h->N, 0);
+    h->v2_vn_edge.assign((size_t)h->N * 2, -1);
+    for (int e = 0; e < h->E; ++e) {
+        const int v = h->cn_vn[e];
+        if (deg[v] >= 2) return fail(EMS_EUNSUPPORTED, "v2 flavour: variable node %d has more than 2 edges (v2.c:2157 handles dv = 2 only)", v);
+        h->v2_vn_edge[(size_t)v * 2 + deg[v]++] = e;                       // NtoB, edges numbered row by row (v2.c:690-697)
+    }
+    for (int v = 0; v < h->N; ++v)
+        if (deg[v] != 2) return fail(EMS_EUNSUPPORTED, "v2 flavour: variable node %d has %d edges, 2 required", v, deg[v]);
+    h->v2_t_dst.resize(h->E);
+    for (int i = 0; i < h->M; ++i) {
+        const int m = h->t_cnp[i] & 0xFFFFFF;
+        for (int k = 0; k < h->dc; ++k) {
+            const int e = m * h->dc + k, v = h->cn_vn[e];
+            const int a = h->v2_vn_edge[(size_t)v * 2], b = h->v2_vn_edge[(size_t)v * 2 + 1];
+            h->v2_t_dst[(size_t)i * h->dc + k] = (a == e) ? b : a;         // the first visitor writes the second edge and vice versa
+        }
+    }
+    const size_t B = (size_t)h->max_batch, nm = (size_t)h->nm_alloc;
+    int r;
+    if ((r = h->d_v2_t_dst.upload(h->v2_t_dst)) || (r = h->d_v2_vn_edge.upload(h->v2_vn_edge)) || (r = h->d_v2_like.alloc(B * h->N * h->q)) ||
+        (r = h->d_v2_app.alloc(B * h->N * h->q)) || (r = h->d_v2_vtoc.alloc(B * h->E * nm)) || (r = h->d_v2_ctov.alloc(B * h->E * nm)) ||
+        (r = h->d_v2_vtoci.alloc(B * h->E * nm)) || (r = h->d_v2_ctovi.alloc(B * h->E * nm)) || (r = h->d_v2_hint.alloc(B * h->E)) ||
+        (r = h->d_v2_stage_like.alloc(B * h->N * h->q)) || (r = h->d_v2_stage_idx.alloc(B * h->N * h->q)) || (r = h->d_v2_bad.alloc(1)))
+        return r;
+    h->v2_ready = true;
+    return EMS_OK;
+}
+
+int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!like || !like_idx) return fail(EMS_EINVAL, "null likelihood pointer");
+    if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
+    if ((r = v2_prepare(h))) return r;
+    const size_t n = (size_t)B * h->N * h->q;
+    HIP_TRY(hipMemcpyAsync(h->d_v2_stage_like.p, like, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_v2_stage_idx.p, like_idx, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_v2_bad.p, 0, sizeof(int), h->stream));
+    HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
+                               h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->d_v2_bad.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad) return fail(EMS_EINVAL, "v2 flavour: likelihood_index must hold a permutation of 0..GF-1 per node");
+    return EMS_OK;
+}
+
+int ems_v2_decode(ems_handle *h, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
+    EmsPlan P = h->plan;
+    P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
+    P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
+    P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p;
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(ems_launch_decode_v2(P, B, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    h->have_dec_ev = true;
+    return EMS_OK;
+}
+
+int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *ctov, int *ctovi, float *app)
+{
+    int r = check_batch(h, frame + 1);
+    if (r) return r;
+    if (frame < 0 || !h->v2_ready) return fail(EMS_EINVAL, "bad argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t ne = (size_t)h->E * h->nm_alloc, off = (size_t)frame * ne;
+    if (vtoc) HIP_TRY(hipMemcpy(vtoc, h->d_v2_vtoc.p + off, ne * sizeof(float), hipMemcpyDeviceToHost));
+    if (ctov) HIP_TRY(hipMemcpy(ctov, h->d_v2_ctov.p + off, ne * sizeof(float), hipMemcpyDeviceToHost));
+    if (vtoci) {
+        std::vector<uint8_t> t(ne);
+        HIP_TRY(hipMemcpy(t.data(), h->d_v2_vtoci.p + off, ne, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ne; ++i) vtoci[i] = t[i];
+    }
+    if (ctovi) {
+        std::vector<int16_t> t(ne);
+        HIP_TRY(hipMemcpy(t.data(), h->d_v2_ctovi.p + off, ne * sizeof(int16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ne; ++i) ctovi[i] = t[i];
+    }
+    if (app) HIP_TRY(hipMemcpy(app, h->d_v2_app.p + (size_t)frame * h->N * h->q, sizeof(float) * (size_t)h->N * h->q, hipMemcpyDeviceToHost));
+    return EMS_OK;
+}
 
 int ems_level_schedule(const ems_code_desc *code, int *n_levels, int *level_ptr, int *order)
 {

@@ -11,6 +11,9 @@ int ems_max_waves_for(int dc);                             // waves per workgrou
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 bool ems_has_occ4_kernel(const EmsPlan &P);
+hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
+                              float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st);
+hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st);
 
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,

@@ -750,7 +750,7 @@ template <int N> __device__ __forceinline__ unsigned above_mask(const float (&x)
     return a;
 }
 
-template <int Q, int LPE>
+template <int Q, int LPE, bool RAW = false>
 __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
                                                  int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big, float hint, float &T_out,
                                                  float *drow)
@@ -904,10 +904,14 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
             const bool ok = myv[k] < EMS_SENTINEL;                      // NB_LDPC.c:358-366
             const float v = ok ? myv[k] : EMS_SENTINEL;
             const int g = ok ? (int)mys[k] : 0;
-            const int gi = gf_mul_log(g, lh, Q - 1);
-            const float nv = rank[k] == 0 ? 0.0f : v - v0;
-            big = big || !(nv < 1e4f);
-            inl[rank[k]] = EmsEntry{nv, (unsigned)t_i2b[gi]};
+            if (RAW) {                                                  // (value, symbol index) as selected
+                inl[rank[k]] = EmsEntry{v, (unsigned)g};
+            } else {
+                const int gi = gf_mul_log(g, lh, Q - 1);
+                const float nv = rank[k] == 0 ? 0.0f : v - v0;
+                big = big || !(nv < 1e4f);
+                inl[rank[k]] = EmsEntry{nv, (unsigned)t_i2b[gi]};
+            }
         }
     }
     if (rowact && rl < 2) inl[nm + rl] = EmsEntry{__builtin_inff(), EMS_S_INVALID};   // list pads
@@ -1226,6 +1230,322 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
+    }
+}
+
+// ================================================================================================
+// v2 flavour: the decode core of EMS_HS_L-BubbleCheck_UBS_decoder_v2.c --
+// max-is-best log-likelihoods, nm-long messages in both directions, 4-candidate bubble check, the same
+// horizontal schedule.  Oracle: oracle/ems_v2_oracle.c (pinned against the real functions).
+// One wave per check-node visit as in k_decode; first version: literal elementary steps (one lane per
+// task, v2.c:1547-1701), the variable-node update (DataPassLog, v2.c:1513-1545) on the selection
+// machinery of the main path (the nm largest of x = the nm smallest of -x, negation is exact).
+// ================================================================================================
+#define V2_INVALID_V (-1000.0f)
+
+// v2.c:1547-1701 on one lane.  in1/in2/out: LDS lists of nm (value, symbol) entries, symbol = binary image, bit 8
+// = "index -1".  seen: q words, all zero on entry (left dirty: the caller clears before the next stage).
+__device__ __forceinline__ int es_v2_task(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *seen, int nm,
+                                          int nbOper, bool has)
+{
+    float c0 = 0, c1 = 0, c2 = 0, c3 = 0;               // tab_comp[0][.]
+    int r0 = 0, r1 = 1, r2 = 2, r3 = 2, k0 = 0, k1 = 0, k2 = 0, k3 = 1;   // rows / columns (:1620-1631)
+    if (has) {
+        for (int i = 0; i < nm; ++i) out[i] = EmsEntry{V2_INVALID_V, EMS_S_INVALID};   // :1590-1593
+        const float b0 = in2[0].v;
+        c0 = in1[0].v + b0; c1 = in1[1].v + b0; c2 = in1[2].v + b0; c3 = in1[2].v + in2[1].v;
+    }
+    int s = 0;
+    bool act = has;
+    for (int ss = 0; ss < nbOper; ++ss) {                // :1648
+        if (__ballot(act) == 0ull) break;
+        // maximum() (:1705-1720): first strict maximum above 0.0, else competitor 0
+        float aux = 0.0f;
+        int pos = 0;
+        if (c0 > aux) { aux = c0; pos = 0; }
+        if (c1 > aux) { aux = c1; pos = 1; }
+        if (c2 > aux) { aux = c2; pos = 2; }
+        if (c3 > aux) { aux = c3; pos = 3; }
+        const int r = pos == 0 ? r0 : (pos == 1 ? r1 : (pos == 2 ? r2 : r3));
+        const int c = pos == 0 ? k0 : (pos == 1 ? k1 : (pos == 2 ? k2 : k3));
+        const float v = pos == 0 ? c0 : (pos == 1 ? c1 : (pos == 2 ? c2 : c3));
+        EmsEntry e1 = EmsEntry{0.0f, EMS_S_INVALID}, e2 = e1;
+        if (act) { e1 = in1[r]; e2 = in2[c]; }
+        if (act && ((e1.s | e2.s) & EMS_S_INVALID)) act = false;           // :1653-1656 break
+        if (act) {
+            const unsigned sym = (e1.s ^ e2.s) & 0xFFu;                       // ADDGF = XOR of binary images
+            if (seen[sym] == 0u) {                                            // :1662-1667
+                out[s] = EmsEntry{v, sym};
+                seen[sym] = 1u;
+                ++s;
+            }
+            if (s == nm) act = false;                                         // :1669
+        }
+        if (act && (r >= nm - 1 || c >= nm - 1)) act = false;                 // :1674-1677
+        if (act) {                                                            // :1682-1688
+            const int u = pos >> 1;
+            const int nr = r + u, nc = c + 1 - u;
+            const float nv = in1[nr].v + in2[nc].v;
+            if (pos == 0) { r0 = nr; k0 = nc; c0 = nv; }
+            else if (pos == 1) { r1 = nr; k1 = nc; c1 = nv; }
+            else if (pos == 2) { r2 = nr; k2 = nc; c2 = nv; }
+            else { r3 = nr; k3 = nc; c3 = nv; }
+        }
+    }
+    if (has && s > 0) {                                                       // :1692-1693 normalisation to the last valid entry
+        const float last = out[s - 1].v;
+        for (int i = 0; i < s; ++i) out[i].v = out[i].v - last;
+    }
+    return s;
+}
+
+template <int Q>
+__device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, int f, int cn, int task, int vn, int lh,
+                                              const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
+                                              EmsEntry *lists, int *lens, const uint2 *sched, int oid, int lane)
+{
+    constexpr int LPE = 16;
+    using G = Geo<Q, LPE>;
+    const int rl = lane & (LPE - 1), row = lane / LPE;
+    const bool rowact = row < C.dc;
+    const int t = rowact ? row : C.dc - 1;
+    const int nm = C.nm, nmp = list_stride(nm), qm1 = Q - 1;
+    const int edge = cn * C.dc + t;
+    const size_t eb = (size_t)f * P.E;
+    float *drow = dense + row * Q;
+
+    // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
+    EmsEntry *inl = lists + t * nmp;
+    for (int k = rl; k < nmp; k += LPE) {
+        EmsEntry e = EmsEntry{__builtin_inff(), EMS_S_INVALID};
+        if (k < nm) {
+            const float v = P.v2_vtoc[(eb + edge) * nm + k];
+            const int g = P.v2_vtoci[(eb + edge) * nm + k];
+            e = EmsEntry{v, (unsigned)t_i2b[gf_mul_log(g, lh, qm1)]};
+        }
+        if (rowact) inl[k] = e;
+    }
+    wave_lds_sync();
+
+    // ---- forward / backward / merge elementary steps (:1798-1850), one lane per task ----
+    unsigned *seen = reinterpret_cast<unsigned *>(dense);
+    for (int st = 1; st <= C.nsteps; ++st) {
+        for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
+        wave_lds_sync();
+        const uint2 tk = sched[(st - 1) * 8 + (lane & 7)];
+        const bool has = lane < 4 && (tk.y >> 16) != 0u;
+        uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
+        const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (tk.x & 0xFFFFu));
+        const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (tk.x >> 16));
+        EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (tk.y & 0xFFFFu));
+        const int s = es_v2_task(in1, in2, out, seen + (lane & 3) * Q, nm, C.nbOper, has);
+        if (has) lens[(int)(tk.y >> 16) - 1] = s;
+        wave_lds_sync();
+    }
+
+    // ---- outputs: inverse rotation over the valid prefix (:1854-1870), C->V record (:2135-2141) ----
+    const EmsEntry *ol = lists + oid * nmp;
+    const int stp = (C.dc == 2) ? nm : lens[oid];
+    for (int k = rl; k < nm; k += LPE) {
+        const EmsEntry e = ol[k];
+        const bool valid = k < stp;
+        if (rowact) {
+            P.v2_ctov[(eb + edge) * nm + k] = e.v;
+            P.v2_ctovi[(eb + edge) * nm + k] = valid ? (int16_t)gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1) : (int16_t)-1;
+        }
+    }
+
+    // ---- DataPassLog (:1513-1545) for my edge's variable node; result goes to its OTHER edge (:2159-2162) ----
+    float x[G::EPL];
+    load_row<Q, LPE>(P.v2_like + ((size_t)f * P.N + vn) * Q, rl, x);
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) x[e] = x[e] - C.offset;                 // :1524
+    store_row<Q, LPE>(drow, rl, x);
+    wave_lds_sync();
+    for (int k = rl; k < stp; k += LPE) {                                     // :1526-1531 (stops at the first -1)
+        const EmsEntry e = ol[k];
+        const int g = gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1);
+        drow[g] = drow[g] + e.v + C.offset;
+    }
+    wave_lds_sync();
+    load_row<Q, LPE>(drow, rl, x);
+    float mvc[G::EPL];
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) mvc[e] = -x[e];                          // the nm largest of x = the nm smallest of -x
+    wave_lds_sync();
+    bool big = false;
+    float T_sel = __builtin_inff();
+    const float hint = P.v2_hint[eb + edge];
+    if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
+        select_rounds<Q, LPE>(mvc, inl, rl, nm);
+    }
+    wave_lds_sync();
+    if (rowact && rl == 0) P.v2_hint[eb + edge] = T_sel;
+    const int dst = P.t_dst[task * C.dc + t];
+    const float last = -inl[nm - 1].v;                                        // :1545 normalisation to the nm-th value
+    for (int k = rl; k < nm; k += LPE) {
+        const EmsEntry e = inl[k];
+        if (rowact) {
+            P.v2_vtoc[(eb + dst) * nm + k] = (-e.v) - last;
+            P.v2_vtoci[(eb + dst) * nm + k] = (uint8_t)e.s;
+        }
+    }
+    wave_lds_sync();
+}
+
+// ComputeAPPLog + Decision (v2.c:1887-1921, :1961-1975) for variable node n on one row of 16 lanes.
+template <int Q>
+__device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, int f, int n, bool active, float *drow, int rl, bool store)
+{
+    constexpr int LPE = 16;
+    using G = Geo<Q, LPE>;
+    const int nm = C.nm;
+    const size_t eb = (size_t)f * P.E;
+    float a[G::EPL];
+    load_row<Q, LPE>(P.v2_like + ((size_t)f * P.N + n) * Q, rl, a);           // APP[n][index] = likelihood (:1907-1908)
+    for (int tt = 0; tt < 2; ++tt) {                                          // its edges in interleaver order (:1910-1913)
+        const int e = P.vn_edge[n * 2 + tt];
+        fill_row<Q, LPE>(drow, rl, -C.offset);                                // TMP = -offset (:1899-1900)
+        wave_lds_sync();
+        for (int k = rl; k < nm; k += LPE) {
+            const int g = P.v2_ctovi[(eb + e) * nm + k];
+            if (g >= 0) drow[g] = P.v2_ctov[(eb + e) * nm + k];               // :1901-1903 (every valid entry, no break)
+        }
+        wave_lds_sync();
+        float c[G::EPL];
+        load_row<Q, LPE>(drow, rl, c);
+#pragma unroll
+        for (int i = 0; i < G::EPL; ++i) a[i] = a[i] + c[i];
+        wave_lds_sync();
+    }
+    if (store && active) store_row<Q, LPE>(P.v2_app + ((size_t)f * P.N + n) * Q, rl, a);
+    // Decision: first strict maximum from symbol 0 = the row maximum at its lowest symbol
+    float neg[G::EPL];
+#pragma unroll
+    for (int i = 0; i < G::EPL; ++i) neg[i] = -a[i];
+    const float lv = row_minmax_f<LPE, false>(array_min_f(neg));
+    unsigned lgu = 0x7FFFFFFFu;
+#pragma unroll
+    for (int i = G::EPL - 1; i >= 0; --i) lgu = (neg[i] == lv) ? (unsigned)G::sym_of(i, rl) : lgu;
+    const unsigned lg = row_min_u<LPE>(lgu);
+    if (active && rl == 0) (P.decide + (size_t)f * P.N)[n] = (uint8_t)lg;
+}
+
+template <int Q>
+__global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
+{
+    constexpr int LPE = 16;
+    using G = Geo<Q, LPE>;
+    Cfg C;
+    C.dc = P.dc; C.nm = P.nm; C.nbOper = P.nbOper; C.T1 = 0; C.q = Q; C.nsteps = C.dc - 2;
+    C.n_lists = C.dc + 3 * (C.dc - 2); C.offset = P.offset;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *t_i2b = smem, *t_b2i = smem + Q;
+    unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
+    unsigned *next_task = first_bad + 1, *spin_fail = first_bad + 2;
+    uint2 *sched = reinterpret_cast<uint2 *>(smem + 2 * Q + 16);
+    uint8_t *done = smem + 2 * Q + 16 + CN_SCHED_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.x;
+    const int rl = lane & (LPE - 1), row = lane / LPE;
+    const int trow = row < C.dc ? row : C.dc - 1;
+    const int oid = P.out_list[trow];
+    uint8_t *wbase = smem + wg_header_bytes(Q, P.M) + (size_t)wave * P.wave_lds_bytes;
+    float *dense = reinterpret_cast<float *>(wbase);
+    constexpr int SURV_BYTES = G::NROWS * surv_stride(LPE) * 8;
+    EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
+    int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
+    for (int i = tid; i < Q; i += blockDim.x) { t_i2b[i] = P.idx2bin[i]; t_b2i[i] = P.bin2idx[i]; }
+    for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
+    cn_sched_build(sched, C.dc, C.nm, tid, blockDim.x);
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
+    __syncthreads();
+
+    int it = 0;
+    unsigned synd = 0;
+    for (int sweep = 0; sweep < P.nsweeps; ++sweep) {                      // iter = 0..NbIterMax (v2.c:2119)
+        const unsigned tag = (unsigned)(sweep + 1) & 0xFFu;
+        auto claim = [&]() {
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(next_task, 1u);
+            return (int)__builtin_amdgcn_readfirstlane((int)i);
+        };
+        int cur = claim();
+        while (cur < P.M) {                                                // check nodes in dependency order (:2122)
+            const int cn = P.t_cn[cur] & 0xFFFFFF;
+            const int vn = P.t_vn[cur * C.dc + trow], lh = P.t_lh[cur * C.dc + trow], pred = P.t_pred[cur * C.dc + trow];
+            const int pp = (rl == 0 && row < C.dc) ? pred : -1;
+            unsigned spins = 0;
+            for (;;) {
+                const bool ok = pp < 0 || __hip_atomic_load(&done[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tag;
+                if (__ballot(!ok) == 0ull) break;
+                if (++spins > (1u << 24)) { if (lane == 0) atomicOr(spin_fail, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, sched, oid, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cur = claim();
+        }
+        __syncthreads();
+        if (tid == 0) *next_task = 0;
+        // ---- ComputeAPPLog + Decision (:2247-2248): four variable nodes per wave at a time ----
+        const int nwaves = (int)(blockDim.x >> 6);
+        for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {
+            const int n = n0 + row;
+            app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + row * Q, rl, false);
+        }
+        __syncthreads();
+        // ---- Syndrom (:1934-1949): value of the first check with a non-zero sum ----
+        for (int c = tid; c < P.M; c += blockDim.x) {
+            unsigned acc = 0;
+            for (int i = 0; i < C.dc; ++i) {
+                const int ed = c * C.dc + i;
+                const int xx = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
+                acc ^= t_i2b[gf_mul_log(xx, P.cn_lh[ed], Q - 1)];
+            }
+            if (acc) atomicMin(first_bad, ((unsigned)c << 8) | t_b2i[acc]);
+        }
+        __syncthreads();
+        const unsigned fb = *first_bad;
+        __syncthreads();
+        if (tid == 0) *first_bad = 0xFFFFFFFFu;
+        synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        it = sweep + 1;
+        if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
+            for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {
+                const int n = n0 + row;
+                app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + row * Q, rl, true);
+            }
+        }
+        if ((synd == 0 && P.early_exit)) break;
+    }
+    if (tid == 0) {
+        P.iters[f] = *spin_fail ? -1 : it;
+        P.synd[f] = (int)synd;
+    }
+}
+
+// builds the symbol-indexed likelihood rows and the initial V->C messages (v2.c:2101-2113) from the sorted layout
+__global__ void k_v2_init(const float *__restrict__ like, const int *__restrict__ like_idx, int N, int q, int nm, int E,
+                          const int *__restrict__ vn_edge, float *__restrict__ likeS, float *__restrict__ vtoc,
+                          uint8_t *__restrict__ vtoci, float *__restrict__ hint, int *__restrict__ bad)
+{
+    const size_t fn = blockIdx.x;                         // (frame, node)
+    const int f = (int)(fn / N), n = (int)(fn % N);
+    for (int g = threadIdx.x; g < q; g += blockDim.x) {
+        const int s = like_idx[fn * q + g];
+        if (s < 0 || s >= q) { atomicOr(bad, 1); continue; }
+        likeS[fn * q + s] = like[fn * q + g];
+    }
+    for (int i = threadIdx.x; i < 2 * nm; i += blockDim.x) {
+        const int tt = i / nm, k = i - tt * nm;
+        const int e = vn_edge[n * 2 + tt];
+        const int s = like_idx[fn * q + k];
+        vtoc[((size_t)f * E + e) * nm + k] = like[fn * q + k];
+        vtoci[((size_t)f * E + e) * nm + k] = (uint8_t)(s & 0xFF);
+        if (k == 0) hint[(size_t)f * E + e] = __builtin_inff();
     }
 }
 
@@ -1578,3 +1898,25 @@ hipError_t ems_debug_counters(unsigned long long *out8, int reset)
     return hipSuccess;
 }
 #endif
+
+// ---- v2 flavour launchers ----
+hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
+                              float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_v2_init, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, like, like_idx, N, q, nm, E, vn_edge, likeS, vtoc, vtoci, hint, bad);
+    return hipGetLastError();
+}
+hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st)
+{
+    if (ems_lpe_for(P.dc) != 16 || P.dc < 2) return hipErrorInvalidValue;
+    const size_t lds = ems_wg_lds_bytes(P.q, P.M, P.wave_lds_bytes, P.waves_per_wg);
+    hipError_t e;
+    if (P.q == 256) {
+        if ((e = set_max_lds(k_decode_v2<256>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_v2<256>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    } else if (P.q == 64) {
+        if ((e = set_max_lds(k_decode_v2<64>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_v2<64>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}

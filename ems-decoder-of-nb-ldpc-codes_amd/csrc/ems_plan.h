@@ -65,4 +65,14 @@ struct EmsPlan {
     int waves_per_wg;
     int occ4;               // launch the 128-VGPR build (four 4-wave workgroups per CU), see ems_core.cpp waves_for_batch
     unsigned long long *stamps; // diagnostic builds only (EMS_STAMPS), else null
+    // ---- v2 flavour (truncated messages both ways, max-is-best; EMS_HS_L-BubbleCheck_UBS_decoder_v2.c) ----
+    const float *v2_like;   // [B][N][q]  likelihood of symbol g of node n (decoder.likelihood scattered by likelihood_index)
+    float *v2_vtoc;         // [B][E][nm] V->C values, edges in row order
+    uint8_t *v2_vtoci;      // [B][E][nm] their symbols (always valid)
+    float *v2_ctov;         // [B][E][nm] C->V values (-1000 where the symbol is -1)
+    int16_t *v2_ctovi;      // [B][E][nm] their symbols, -1 = none
+    float *v2_hint;         // [B][E]     last selection threshold of the edge's variable-node update (search start only)
+    float *v2_app;          // [B][N][q]  APP of the last iteration run (ComputeAPPLog)
+    const int *t_dst;       // [M*dc]     per (task, edge): row-order id of the OTHER edge of its variable node (dv = 2)
+    const int *vn_edge;     // [N][2]     NtoB: the two edges of a variable node in row order
 };

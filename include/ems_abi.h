@@ -100,6 +100,20 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov /*[E][GF]*/); /* decoder_
 /* channel.c:78-91: the ascending (LLR, symbol) form of frame `frame`'s channel LLRs, as
  * decoder_t.intrinsic_LLR / intrinsic_GF hold it ([N][GF] each); valid after ems_llr_init. */
 int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
+/* ---- v2 flavour: the decode core of EMS_HS_L-BubbleCheck_UBS_decoder_v2.c ----
+ * Max-is-best log-likelihoods, nm-long messages both ways, 4-candidate bubble check (v2.c:1547), horizontal
+ * schedule (v2.c:2119-2253).  Same handle (ems_create: nm, NbOper, offset, NbIterMax, early_exit); the decode
+ * runs iterations iter = 0..NbIterMax inclusive like the reference's loop.  Needs dv = 2 (the reference's Flag
+ * trick, v2.c:2157), regular check degree <= 4, GF(64) or GF(256).
+ *   like / like_idx: [B][N][GF], per node the GF likelihoods in decreasing order and their symbols, i.e.
+ *   decoder.likelihood / decoder.likelihood_index as ModelChannelAWGN leaves them (v2.c:1483-1497).
+ *   Results through ems_get_results (decide, iterations executed, syndrome). */
+int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx, int B);
+int ems_v2_decode(ems_handle *h, int B);
+/* decoder.VtoC / VtoCindex / CtoV / CtoVindex ([E][nm], edges numbered row by row) and decoder.APP ([N][GF]) of one
+ * frame after ems_v2_decode; any pointer may be NULL. */
+int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *ctov, int *ctovi, float *app);
+
 /* Level schedule of the layered sweep: check nodes grouped so that no two in a level share a variable
  * node; visiting levels in order reproduces the sequential order of NB_LDPC.c:320 exactly. */
 int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr /*[M+1] or NULL*/, int *order /*[M] or NULL*/);

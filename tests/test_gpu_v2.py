@@ -1,0 +1,93 @@
+"""GPU parity of the v2 flavour through the C ABI (ems_v2_*): against the oracle
+restatement (oracle/ems_v2_oracle.c, pinned to the real v2 functions) on seeded likelihoods, and against the
+reference-generated golden frames of tests/golden/v2_frames.npz."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import MAT, ROOT, gold
+
+pytestmark = pytest.mark.gpu
+STATE = ("vtoc", "vtoci", "ctov", "ctovi", "app")
+
+
+@pytest.fixture(scope="module")
+def v2(orc):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    return importlib.import_module("orc_v2")
+
+
+def _check_frames(pkg, v2, mat, q, logq, nm, nop, off, itmax, cases, early_exit=True, full_state=True):
+    path = os.path.join(MAT, mat)
+    o = v2.V2Oracle(path)
+    pairs = [v2.synthetic_likelihood(o.N, q, logq, o.o.idx2bin, sg, seed) for sg, seed in cases]
+    like = np.stack([p[0] for p in pairs])
+    idx = np.stack([p[1] for p in pairs])
+    dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=len(cases), early_exit=early_exit)
+    decide, iters, synd = dec.v2_decode_batch(like, idx)
+    out = []
+    for b in range(len(cases)):
+        ref = o.decode(like[b], idx[b], nm, nop, off, itmax, early_exit=early_exit)
+        assert iters[b] == ref["iters"] and synd[b] == ref["synd"], (b, iters[b], ref["iters"], synd[b], ref["synd"])
+        assert (decide[b] == ref["decide"]).all(), "frame %d: hard decisions differ" % b
+        if full_state:
+            st = dec.v2_state(b)
+            for k in STATE:
+                assert st[k].tobytes() == ref[k].tobytes(), "frame %d: %s differs" % (b, k)
+        out.append(ref)
+    dec.close()
+    return out
+
+
+def test_v2_small_code_vs_oracle(pkg, v2):
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 12, 24, 0.5, 12, [(0.7, 1), (0.95, 2), (1.3, 3), (0.85, 4), (1.0, 5), (0.6, 6)])
+
+
+def test_v2_small_code_other_parameters(pkg, v2):
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 16, 48, 0.3, 6, [(0.9, 11), (1.2, 12)])
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 8, 8, 1.0, 5, [(0.9, 13), (0.75, 14)], early_exit=False)
+
+
+def test_v2_big_code_vs_oracle(pkg, v2):
+    _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
+
+
+def test_v2_golden_frames_from_the_reference(pkg, orc, v2):
+    g = gold("v2_frames.npz")
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = v2.V2Oracle(path)
+    code = pkg.Code(path)
+    for i, (sg, seed, itmax) in enumerate(g["big_cases"]):
+        like, idx = v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, float(sg), int(seed))
+        dec = pkg.Decoder(code, 20, 40, 0.3, int(itmax), max_batch=1)
+        d, it, sy = dec.v2_decode_batch(like[None], idx[None])
+        meta = g["big%d_meta" % i]
+        assert it[0] == meta[0] and sy[0] == meta[1] and (d[0].astype(np.uint8) == g["big%d_decide" % i]).all()
+        st = dec.v2_state(0)
+        assert [orc.crc32(st[k]) for k in STATE] == [int(x) for x in meta[2:]]
+        dec.close()
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = v2.V2Oracle(path)
+    code = pkg.Code(path)
+    for i, (sg, seed) in enumerate(g["small_cases"]):
+        like, idx = v2.synthetic_likelihood(o.N, 64, 6, o.o.idx2bin, float(sg), int(seed))
+        dec = pkg.Decoder(code, 12, 24, 0.5, 12, max_batch=1)
+        d, it, sy = dec.v2_decode_batch(like[None], idx[None])
+        assert it[0] == g["small%d_meta" % i][0] and sy[0] == g["small%d_meta" % i][1]
+        st = dec.v2_state(0)
+        for k in STATE:
+            assert st[k].tobytes() == g["small%d_%s" % (i, k)].tobytes(), (i, k)
+        dec.close()
+
+
+def test_v2_rejects_what_it_does_not_build(pkg, v2):
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")            # dc = 8, GF(16)
+    dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 5, max_batch=1)
+    o = v2.V2Oracle(path)
+    like, idx = v2.synthetic_likelihood(o.N, 16, 4, o.o.idx2bin, 0.8, 1)
+    with pytest.raises(pkg.EmsError):
+        dec.v2_load_likelihood(like[None], idx[None])
+    dec.close()
