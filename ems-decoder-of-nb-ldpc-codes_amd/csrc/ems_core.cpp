@@ -642,6 +642,7 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf)
 // ------------------------------------------------------------------------------------------------
 // v2 flavour (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c): same handle, own state.
 // ------------------------------------------------------------------------------------------------
+static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P);
 static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
@@ -703,6 +704,7 @@ int ems_v2_decode(ems_handle *h, int B)
     if (r) return r;
     if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
     EmsPlan P = h->plan;
+    shape_for_batch(h, B, P);                                           // 4-wave workgroups, 3 frames per CU, for big batches
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
     P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p;
