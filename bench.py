@@ -34,6 +34,9 @@ WORKLOADS = {
     "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1024),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
+    # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
+    # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (oracle/orc_v2.synthetic_likelihood, sigma 0.95)
+    "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 768),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -42,6 +45,103 @@ def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):
     """per sweep every edge reads+writes one dense fp32 APP row and one compact C->V
     message (nm (f32,u8) pairs + a default)."""
     return sweeps * (2 * E * q * 4 + 2 * E * min(q * 4, nm * 5 + 4))
+
+
+def algorithmic_bytes_per_frame_decode_v2(N, E, q, nm, iters):
+    """v2 flavour, per iteration: every edge reads its V->C message, its node's likelihood row, writes its C->V message
+    and the other edge's V->C message (nm (f32,u8) pairs each); ComputeAPPLog + Decision read every node's likelihood
+    row and its two C->V messages and write one decision byte."""
+    return iters * (E * (q * 4 + 3 * nm * 5) + N * (q * 4 + 2 * nm * 5 + 1))
+
+
+def cpu_baseline_v2(v2, matrix, nm, nop, off, itmax, sigma, threads):
+    from concurrent.futures import ThreadPoolExecutor
+    o = v2.V2Oracle(matrix)
+    frames = [v2.synthetic_likelihood(o.N, o.q, o.logq, o.o.idx2bin, sigma, 100 + i) for i in range(threads)]
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda fr: o.decode(fr[0], fr[1], nm, nop, off, itmax, early_exit=False)["iters"], frames))
+    dt = time.time() - t0
+    return {"value": round(threads / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames (1 per thread), v2 oracle, fixed work %d iterations, %.1f s wall" % (threads, itmax + 1, dt)}
+
+
+def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
+    """The v2 flavour's line: same contract, the step is init-from-staged-likelihoods + k_decode_v2 + results."""
+    import importlib as il
+    orc = ge.load_oracle()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    v2 = il.import_module("orc_v2")
+    mat, nm, nop, off, itmax, _e, B0 = WORKLOADS["gf256_v2"]
+    B = a.batch or B0
+    matrix = os.path.join(ge.MATRICES, mat)
+    code = pkg.Code(matrix)
+    o = v2.V2Oracle(matrix)
+    sigma = 0.95
+    t_setup = time.time()
+    base = [v2.synthetic_likelihood(o.N, o.q, o.logq, o.o.idx2bin, sigma, 1000 * rank + s) for s in range(8)]
+    like = np.stack([base[i % 8][0] for i in range(B)])
+    idx = np.stack([base[i % 8][1] for i in range(B)])
+    t_setup = time.time() - t_setup
+    dec = pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False)
+    dec.v2_load_likelihood(like, idx)                  # staged in HBM before the timed region
+    dec.synchronize()
+    counters = torch.zeros(3, dtype=torch.int64, device="cuda")
+
+    def step():
+        dec.v2_reinit(B)
+        dec.v2_decode(B)
+        it = np.zeros(B, np.int32); sy = np.zeros(B, np.int32)
+        pkg._check(pkg.lib().ems_get_results(dec.h, B, None, pkg._ptr(it), pkg._ptr(sy)))
+        counters.copy_(torch.tensor([B, int((sy != 0).sum()), int(it.sum())], dtype=torch.int64))
+        if dist is not None:
+            dist.all_reduce(counters)
+        return dec.last_decode_ms, dec.last_llr_ms
+
+    def fence():
+        dec.synchronize(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kms, lms = [], []
+    for _ in range(a.steps):
+        k, l = step(); kms.append(k); lms.append(l)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        alg = algorithmic_bytes_per_frame_decode_v2(code.N, code.E, code.GF, nm, itmax + 1) * B
+        kavg = float(np.mean(kms)) * 1e-3
+        out = {"metric": "decoded frames/sec, v2 flavour (truncated messages both ways) @ N=64800 GF(256) R=1/2, nm=20, 29 iterations",
+               "value": round(world * B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic: seeded max-is-best likelihoods of an all-zero BPSK/AWGN codeword, sigma %.2f, 8 distinct frames tiled" % sigma,
+               "config": {"workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
+                          "batch_per_gpu": B, "sharding": "independent frames", "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
+                          "frames_nonzero_syndromes_sumiter": counters.cpu().tolist()},
+               "roofline": {"bound": "hbm", "kernel": "k_decode_v2 (persistent, 1 workgroup per frame, %d frames per launch)" % B,
+                            "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
+               "host_setup_s": round(t_setup, 1)}
+        tr = os.path.join(ROOT, "profiles", "traffic_gf256_v2.json")
+        if os.path.exists(tr):
+            try:
+                out["roofline"]["traffic"] = int(json.load(open(tr))["hbm_bytes_per_frame"] * B)
+            except Exception:
+                pass
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_v2(v2, matrix, nm, nop, off, itmax, sigma, max(1, min(os.cpu_count() or 1, 16)))
+        print(json.dumps(out), flush=True)
+    dec.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads):
@@ -109,6 +209,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pkg = ge.load_package()
+    if a.workload == "gf256_v2":
+        return bench_v2(a, pkg, ge, torch, dist, rank, world, local)
     harness = importlib.import_module(ge.PKG_NAME + ".harness")
     mat, nm, nop, off, itmax, ebn, B0 = WORKLOADS[a.workload]
     B = a.batch or B0

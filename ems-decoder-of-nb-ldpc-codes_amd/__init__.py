@@ -213,6 +213,9 @@ class Decoder:
     def v2_decode(self, B):
         _check(lib().ems_v2_decode(self.h, B))
 
+    def v2_reinit(self, B):
+        _check(lib().ems_v2_reinit(self.h, B))
+
     def v2_decode_batch(self, like, like_idx):
         B = self.v2_load_likelihood(like, like_idx)
         self.v2_decode(B)

@@ -698,6 +698,21 @@ int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx
     return EMS_OK;
 }
 
+/* re-runs the initialisation (symbol-indexed likelihoods, V->C = nm best likelihoods, v2.c:2101-2113) from the
+ * likelihoods staged in HBM by the last ems_v2_load_likelihood: the bench's "inputs already resident" step */
+int ems_v2_reinit(ems_handle *h, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
+                               h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_llr_ev = true;
+    return EMS_OK;
+}
+
 int ems_v2_decode(ems_handle *h, int B)
 {
     int r = check_batch(h, B);

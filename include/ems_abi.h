@@ -110,6 +110,9 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
  *   Results through ems_get_results (decide, iterations executed, syndrome). */
 int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx, int B);
 int ems_v2_decode(ems_handle *h, int B);
+/* initialisation again from the likelihoods already staged in HBM by the last ems_v2_load_likelihood (timed with
+ * ems_last_llr_ms): lets a harness repeat a decode without the host upload */
+int ems_v2_reinit(ems_handle *h, int B);
 /* decoder.VtoC / VtoCindex / CtoV / CtoVindex ([E][nm], edges numbered row by row) and decoder.APP ([N][GF]) of one
  * frame after ems_v2_decode; any pointer may be NULL. */
 int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *ctov, int *ctovi, float *app);
