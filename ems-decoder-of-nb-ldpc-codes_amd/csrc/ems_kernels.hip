@@ -235,6 +235,7 @@ __device__ __forceinline__ unsigned red8_minu(unsigned x)
 // Register-light form of es_post for the rare continuation (T up to 64 picks): same algorithm, the
 // per-pick value/symbol are recomputed in each of the three passes instead of being kept in registers.
 // (p, gbase: lane within / first lane of the task's 16 lanes.)
+template <int FL = 0>
 __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
                                            const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
                                            int nbOper, int &S_out)
@@ -244,7 +245,8 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
         const unsigned pk = picks[ok ? i : 0];
         const int w = pk >> 5;
         k = pk & 31;
-        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
+        constexpr int NFIX = FL ? 2 : 4;                 // row walkers (the others walk down a column)
+        const int r = w < NFIX ? w : k, c = w < NFIX ? k : w - NFIX;
         const EmsEntry e1 = in1[r], e2 = in2[c];
         v = e1.v + e2.v;
         sy = sym_comb(e1.s, e2.s);
@@ -312,7 +314,11 @@ __device__ __forceinline__ int red8_sumi(int x)
 // whichever such head is taken the step is the "source index -1 -> break" stop of bubble_decoder.c:478.
 // A pick is recorded as one byte, competitor p in bits 5..7 and its list position in bits 0..4; the loop
 // carries y = 32 p + pos so that the byte is y itself and the list address is one shift-add away.
-template <bool EXACT>
+// FL = 1: the v2 flavour's comparator (v2.c:1705-1720 on 4 competitors = aligned groups of 4 lanes): first strict
+// maximum above 0.0, competitor 0 when none.  For non-NaN floats "x > 0.0f" <=> "bits as signed int > 0" and positive
+// floats order like their bit patterns, so the comparison runs on signed integers (any negative / zero value simply
+// never wins); p = lane & 3, gbase = lane & ~3.
+template <bool EXACT, int FL = 0>
 __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const EmsEntry *mvy, uint8_t *pk,
                                          uint8_t *dummy, int p, int gbase, int from, int to)
 {
@@ -331,9 +337,19 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
     float b0 = a0, b1 = a1;
     bool wprev = false;
     auto step = [&](float &x0, float &x1, int ss) {
-        const unsigned m = red8_minu(hv);
-        bool iw = (hv == m);
-        if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
+        bool iw;
+        if (FL == 0) {
+            const unsigned m = red8_minu(hv);
+            iw = (hv == m);
+            if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase)) - 1);
+        } else {
+            int m = (int)hv;
+            m = max(m, dpp_i<DPP_XOR1>(m));
+            m = max(m, dpp_i<DPP_XOR2>(m));
+            iw = ((int)hv == m);
+            if (EXACT) iw = (p == __ffs((unsigned)(__ballot(iw) >> gbase) & 0xFu) - 1);
+            iw = (m > 0) ? iw : (p == 0);
+        }
         const float nx = wprev ? x1 : x0;
         (iw ? pk : dummy)[ss] = (uint8_t)y;      // losers write to their own dummy dword (+ss: still one dword per lane)
         y += iw ? 1 : 0;
@@ -359,7 +375,7 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
 // one stage in ten at nm = 20: duplicates eat picks), the merge runs 8 more steps with the exact rule and the
 // new picks go through the same table incrementally -- its first-pass claims are still in place, and a later
 // pick never displaces an earlier one (ds_max of ES_MAX_STEPS - i).  tbl is all-zero on entry and on exit.
-template <int NJ>
+template <int NJ, int FL = 0>
 __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
                                         uint8_t *picks, uint8_t *dummy, int q, int p, int gbase, int p8, int gbase8, bool has, int T, int nm,
                                         int nbOper, int &S_out, unsigned &hv, int &y, float fxv, const EmsEntry *mvy, int &T_done)
@@ -371,7 +387,8 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &li) {
         const unsigned pk = picks[ok ? i : 0];
         const int w = pk >> 5, k = pk & 31;
-        const int r = w < 4 ? w : k, c = w < 4 ? k : w - 4;
+        constexpr int NFIX = FL ? 2 : 4;
+        const int r = w < NFIX ? w : k, c = w < NFIX ? k : w - NFIX;
         const EmsEntry e1 = in1[r], e2 = in2[c];
         v = e1.v + e2.v;
         sy = sym_comb(e1.s, e2.s);
@@ -412,7 +429,7 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     if (__ballot(has && !done) != 0ull) {
         DBG_ADD(4, 1);
         const int T2 = min(T + 8, nbOper);
-        es_merge<true>(hv, y, fxv, mvy, picks, dummy, p8, gbase8, T, T2);
+        es_merge<true, FL>(hv, y, fxv, mvy, picks, dummy, p8, gbase8, T, T2);
         T_done = T2;
         wave_lds_sync();
         const int i = T + p;
@@ -1299,10 +1316,75 @@ __device__ __forceinline__ int es_v2_task(const EmsEntry *in1, const EmsEntry *i
     return s;
 }
 
+__device__ __forceinline__ int red4_sumi(int x)
+{
+    x += dpp_i<DPP_XOR1>(x);
+    x += dpp_i<DPP_XOR2>(x);
+    return x;
+}
+
+// v2 elementary step in the merge + post-pass form of the main path (es_stage_fast): the pick sequence of the
+// 4-candidate bubble (competitors 0,1 walk along rows 0,1; competitors 2,3 walk down columns 0,1 from row 2,
+// v2.c:1620-1631 / :1682-1688) does not depend on the output bookkeeping, so a serial merge records the picks and
+// a parallel post-pass applies the stops (:1653 invalid -> before the pick, :1669 nm outputs, :1674 last row/column
+// -> after it) and the redundancy control (:1662).  A task owns 16 lanes; every aligned group of 4 runs the merge.
+__device__ __forceinline__ void es_stage_fast_v2(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
+                                                 int lane, uint2 task, int nm, int nbOper, int T1)
+{
+    const int p = lane & 3;                         // competitor
+    const int gbase = lane & ~3;
+    const int p16 = lane & 15, gbase16 = lane & ~15, gsel = lane >> 4;
+    const bool has = (task.y >> 16) != 0u;
+    const int o_id = (int)(task.y >> 16) - 1;
+    const int nmp = list_stride(nm);
+    uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
+    const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (task.x & 0xFFFFu));
+    const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (task.x >> 16));
+    EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (task.y & 0xFFFFu));
+    unsigned *tbl = tbl_base + gsel * q;
+    uint8_t *picks = picks_base + gsel * (ES_MAX_STEPS + 4);
+    uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;
+    if (has)
+        for (int k = p16; k < nmp; k += 16) out[k] = EmsEntry{k < nm ? V2_INVALID_V : -__builtin_inff(), EMS_S_INVALID};   // :1590-1593
+    const bool rowc = p < 2;
+    const EmsEntry *mv = rowc ? in2 : in1;
+    const EmsEntry *mvy = mv - 32 * p;
+    const int pos0 = (rowc ? 0 : 2) + 32 * p;
+    const float fxv = rowc ? in1[p].v : in2[p - 2].v;
+    unsigned hv;
+    int pos;
+    auto init = [&]() {
+        pos = pos0;
+        hv = (unsigned)__float_as_int(fxv + mvy[pos0].v);
+    };
+    int S = 0;
+    bool done;
+    init();
+    es_merge<false, 1>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
+    if (__ballot(has && red4_sumi(pos - pos0) != T1) != 0ull) {   // two equal maxima somewhere: redo with the exact rule
+        init();
+        es_merge<true, 1>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
+    }
+    int Td = T1;
+    if (T1 <= 16) done = es_post<1, 1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (T1 <= 32) done = es_post<2, 1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else done = es_post_rt<1>(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
+    if (__ballot(has && !done) != 0ull) {
+        es_merge<true, 1>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
+        es_post_rt<1>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
+    }
+    wave_lds_sync();
+    const float last = (has && S > 0) ? out[S - 1].v : 0.0f;         // :1692-1693 normalisation to the last valid entry
+    wave_lds_sync();
+    if (has)
+        for (int k = p16; k < S; k += 16) out[k].v = out[k].v - last;
+    if (has && p16 == 0) lens[o_id] = S;
+}
+
 template <int Q>
 __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, int f, int cn, int task, int vn, int lh,
                                               const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                              EmsEntry *lists, int *lens, const uint2 *sched, int oid, int lane)
+                                              EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane)
 {
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
@@ -1329,7 +1411,17 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
 
     // ---- forward / backward / merge elementary steps (:1798-1850), one lane per task ----
     unsigned *seen = reinterpret_cast<unsigned *>(dense);
-    for (int st = 1; st <= C.nsteps; ++st) {
+    const bool fast = C.nbOper <= ES_MAX_STEPS;              // pick areas hold 64 steps; longer runs take the literal form
+    if (fast) {
+        for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
+        wave_lds_sync();
+        for (int st = 1; st <= C.nsteps; ++st) {             // 16 lanes per task; the dedupe tables stay clean between stages
+            const uint2 tk = sched[(st - 1) * 8 + (lane >> 4)];
+            es_stage_fast_v2(lists, lens, seen, picks, Q, lane, tk, nm, C.nbOper, C.T1);
+            wave_lds_sync();
+        }
+    }
+    for (int st = 1; !fast && st <= C.nsteps; ++st) {
         for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
         wave_lds_sync();
         const uint2 tk = sched[(st - 1) * 8 + (lane & 7)];
@@ -1437,7 +1529,7 @@ __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     Cfg C;
-    C.dc = P.dc; C.nm = P.nm; C.nbOper = P.nbOper; C.T1 = 0; C.q = Q; C.nsteps = C.dc - 2;
+    C.dc = P.dc; C.nm = P.nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, P.nm + 3); C.q = Q; C.nsteps = C.dc - 2;
     C.n_lists = C.dc + 3 * (C.dc - 2); C.offset = P.offset;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *t_i2b = smem, *t_b2i = smem + Q;
@@ -1455,6 +1547,7 @@ __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4);
     EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + G::NROWS * Q * 4 + SURV_BYTES);
     int *lens = reinterpret_cast<int *>(wbase + G::NROWS * Q * 4 + SURV_BYTES + ((C.n_lists * list_stride(C.nm) * 8 + 15) & ~15));
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((C.n_lists * 4 + 15) & ~15);
     for (int i = tid; i < Q; i += blockDim.x) { t_i2b[i] = P.idx2bin[i]; t_b2i[i] = P.bin2idx[i]; }
     for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
     cn_sched_build(sched, C.dc, C.nm, tid, blockDim.x);
@@ -1483,7 +1576,7 @@ __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, sched, oid, lane);
+            process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             cur = claim();

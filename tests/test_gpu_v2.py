@@ -49,6 +49,8 @@ def test_v2_small_code_vs_oracle(pkg, v2):
 def test_v2_small_code_other_parameters(pkg, v2):
     _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 16, 48, 0.3, 6, [(0.9, 11), (1.2, 12)])
     _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 8, 8, 1.0, 5, [(0.9, 13), (0.75, 14)], early_exit=False)
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 12, 80, 0.5, 6, [(0.9, 15), (1.1, 16)])       # NbOper > 64: literal elementary steps
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 5, 6, 0.5, 6, [(0.9, 17), (1.1, 18)])         # NbOper < nm + 3
 
 
 def test_v2_big_code_vs_oracle(pkg, v2):
