@@ -1523,13 +1523,14 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     if (active && rl == 0) (P.decide + (size_t)f * P.N)[n] = (uint8_t)lg;
 }
 
-template <int Q>
+template <int Q, int NM = 0>
 __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
 {
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     Cfg C;
-    C.dc = P.dc; C.nm = P.nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, P.nm + 3); C.q = Q; C.nsteps = C.dc - 2;
+    C.dc = P.dc; C.nm = NM > 0 ? NM : P.nm; C.nbOper = P.nbOper; C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);   // (NM > 0: nbOper >= NM + 3)
+    C.q = Q; C.nsteps = C.dc - 2;
     C.n_lists = C.dc + 3 * (C.dc - 2); C.offset = P.offset;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *t_i2b = smem, *t_b2i = smem + Q;
@@ -1565,7 +1566,8 @@ __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
         };
         int cur = claim();
         while (cur < P.M) {                                                // check nodes in dependency order (:2122)
-            const int cn = P.t_cn[cur] & 0xFFFFFF;
+            const int cnp = P.t_cn[cur];
+            const int cn = cnp & 0xFFFFFF;
             const int vn = P.t_vn[cur * C.dc + trow], lh = P.t_lh[cur * C.dc + trow], pred = P.t_pred[cur * C.dc + trow];
             const int pp = (rl == 0 && row < C.dc) ? pred : -1;
             unsigned spins = 0;
@@ -1576,6 +1578,12 @@ __global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            switch (cnp >> 24) {                               // static priority from the task's slack (host)
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
             process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2004,7 +2012,10 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st)
     if (ems_lpe_for(P.dc) != 16 || P.dc < 2) return hipErrorInvalidValue;
     const size_t lds = ems_wg_lds_bytes(P.q, P.M, P.wave_lds_bytes, P.waves_per_wg);
     hipError_t e;
-    if (P.q == 256) {
+    if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64) {       // the BASELINE message size, compile-time
+        if ((e = set_max_lds(k_decode_v2<256, 20>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_v2<256, 20>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    } else if (P.q == 256) {
         if ((e = set_max_lds(k_decode_v2<256>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_decode_v2<256>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     } else if (P.q == 64) {
