@@ -36,7 +36,7 @@ WORKLOADS = {
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
     # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
     # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (oracle/orc_v2.synthetic_likelihood, sigma 0.95)
-    "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 768),
+    "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1024),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 

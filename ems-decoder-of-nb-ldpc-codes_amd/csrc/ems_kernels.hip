@@ -1523,8 +1523,8 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     if (active && rl == 0) (P.decide + (size_t)f * P.N)[n] = (uint8_t)lg;
 }
 
-template <int Q, int NM = 0>
-__global__ void __launch_bounds__(768, 1) k_decode_v2(const EmsPlan P)
+template <int Q, int NM = 0, bool OCC4 = false>
+__global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(const EmsPlan P)
 {
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
@@ -2012,7 +2012,10 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st)
     if (ems_lpe_for(P.dc) != 16 || P.dc < 2) return hipErrorInvalidValue;
     const size_t lds = ems_wg_lds_bytes(P.q, P.M, P.wave_lds_bytes, P.waves_per_wg);
     hipError_t e;
-    if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64) {       // the BASELINE message size, compile-time
+    if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && P.occ4 && P.waves_per_wg <= 4) {   // 4 frames per CU
+        if ((e = set_max_lds(k_decode_v2<256, 20, true>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_v2<256, 20, true>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    } else if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64) {       // the BASELINE message size, compile-time
         if ((e = set_max_lds(k_decode_v2<256, 20>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_decode_v2<256, 20>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     } else if (P.q == 256) {

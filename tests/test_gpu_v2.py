@@ -57,6 +57,15 @@ def test_v2_big_code_vs_oracle(pkg, v2):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
 
 
+@pytest.mark.parametrize("waves,occ4", [(4, False), (4, True)])
+def test_v2_big_code_small_workgroup_shapes(pkg, v2, monkeypatch, waves, occ4):
+    """The launch shapes picked for big batches (4-wave workgroups; the 128-VGPR build), forced on two frames."""
+    monkeypatch.setenv("EMS_WAVES", str(waves))
+    if occ4:
+        monkeypatch.setenv("EMS_OCC4", "1")
+    _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
+
+
 def test_v2_golden_frames_from_the_reference(pkg, orc, v2):
     g = gold("v2_frames.npz")
     path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
