@@ -1393,7 +1393,12 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     const int t = rowact ? row : C.dc - 1;
     const int nm = C.nm, nmp = list_stride(nm), qm1 = Q - 1;
     const int edge = cn * C.dc + t;
-    const size_t eb = (size_t)f * P.E;
+    // frame bases are wave-uniform (scalar registers); per-lane parts are 32-bit offsets
+    const size_t fe = (size_t)f * P.E * (size_t)nm;
+    float *const f_vtoc = P.v2_vtoc + fe, *const f_ctov = P.v2_ctov + fe;
+    uint8_t *const f_vtoci = P.v2_vtoci + fe;
+    int16_t *const f_ctovi = P.v2_ctovi + fe;
+    float *const f_hint = P.v2_hint + (size_t)f * P.E;
     float *drow = dense + row * Q;
 
     // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
@@ -1401,8 +1406,8 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     for (int k = rl; k < nmp; k += LPE) {
         EmsEntry e = EmsEntry{__builtin_inff(), EMS_S_INVALID};
         if (k < nm) {
-            const float v = P.v2_vtoc[(eb + edge) * nm + k];
-            const int g = P.v2_vtoci[(eb + edge) * nm + k];
+            const float v = f_vtoc[(unsigned)(edge * nm + k)];
+            const int g = f_vtoci[(unsigned)(edge * nm + k)];
             e = EmsEntry{v, (unsigned)t_i2b[gf_mul_log(g, lh, qm1)]};
         }
         if (rowact) inl[k] = e;
@@ -1442,14 +1447,14 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
         const EmsEntry e = ol[k];
         const bool valid = k < stp;
         if (rowact) {
-            P.v2_ctov[(eb + edge) * nm + k] = e.v;
-            P.v2_ctovi[(eb + edge) * nm + k] = valid ? (int16_t)gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1) : (int16_t)-1;
+            f_ctov[(unsigned)(edge * nm + k)] = e.v;
+            f_ctovi[(unsigned)(edge * nm + k)] = valid ? (int16_t)gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1) : (int16_t)-1;
         }
     }
 
     // ---- DataPassLog (:1513-1545) for my edge's variable node; result goes to its OTHER edge (:2159-2162) ----
     float x[G::EPL];
-    load_row<Q, LPE>(P.v2_like + ((size_t)f * P.N + vn) * Q, rl, x);
+    load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q, rl, x);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) x[e] = x[e] - C.offset;                 // :1524
     store_row<Q, LPE>(drow, rl, x);
@@ -1467,19 +1472,19 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     wave_lds_sync();
     bool big = false;
     float T_sel = __builtin_inff();
-    const float hint = P.v2_hint[eb + edge];
+    const float hint = f_hint[(unsigned)edge];
     if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
     }
     wave_lds_sync();
-    if (rowact && rl == 0) P.v2_hint[eb + edge] = T_sel;
+    if (rowact && rl == 0) f_hint[(unsigned)edge] = T_sel;
     const int dst = P.t_dst[task * C.dc + t];
     const float last = -inl[nm - 1].v;                                        // :1545 normalisation to the nm-th value
     for (int k = rl; k < nm; k += LPE) {
         const EmsEntry e = inl[k];
         if (rowact) {
-            P.v2_vtoc[(eb + dst) * nm + k] = (-e.v) - last;
-            P.v2_vtoci[(eb + dst) * nm + k] = (uint8_t)e.s;
+            f_vtoc[(unsigned)(dst * nm + k)] = (-e.v) - last;
+            f_vtoci[(unsigned)(dst * nm + k)] = (uint8_t)e.s;
         }
     }
     wave_lds_sync();
