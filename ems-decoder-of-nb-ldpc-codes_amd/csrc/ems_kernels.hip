@@ -1497,16 +1497,18 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     const int nm = C.nm;
-    const size_t eb = (size_t)f * P.E;
+    const size_t fe = (size_t)f * P.E * (size_t)nm;
+    const float *const f_ctov = P.v2_ctov + fe;
+    const int16_t *const f_ctovi = P.v2_ctovi + fe;
     float a[G::EPL];
-    load_row<Q, LPE>(P.v2_like + ((size_t)f * P.N + n) * Q, rl, a);           // APP[n][index] = likelihood (:1907-1908)
+    load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)n * (unsigned)Q, rl, a);           // APP[n][index] = likelihood (:1907-1908)
     for (int tt = 0; tt < 2; ++tt) {                                          // its edges in interleaver order (:1910-1913)
         const int e = P.vn_edge[n * 2 + tt];
         fill_row<Q, LPE>(drow, rl, -C.offset);                                // TMP = -offset (:1899-1900)
         wave_lds_sync();
         for (int k = rl; k < nm; k += LPE) {
-            const int g = P.v2_ctovi[(eb + e) * nm + k];
-            if (g >= 0) drow[g] = P.v2_ctov[(eb + e) * nm + k];               // :1901-1903 (every valid entry, no break)
+            const int g = f_ctovi[(unsigned)(e * nm + k)];
+            if (g >= 0) drow[g] = f_ctov[(unsigned)(e * nm + k)];               // :1901-1903 (every valid entry, no break)
         }
         wave_lds_sync();
         float c[G::EPL];
@@ -1515,7 +1517,7 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
         for (int i = 0; i < G::EPL; ++i) a[i] = a[i] + c[i];
         wave_lds_sync();
     }
-    if (store && active) store_row<Q, LPE>(P.v2_app + ((size_t)f * P.N + n) * Q, rl, a);
+    if (store && active) store_row<Q, LPE>(P.v2_app + (size_t)f * P.N * Q + (unsigned)n * (unsigned)Q, rl, a);
     // Decision: first strict maximum from symbol 0 = the row maximum at its lowest symbol
     float neg[G::EPL];
 #pragma unroll
@@ -1570,10 +1572,19 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
             return (int)__builtin_amdgcn_readfirstlane((int)i);
         };
         int cur = claim();
+        int cnp = 0, vn = 0, lh = 0, pred = -1;
+        if (cur < P.M) {
+            cnp = P.t_cn[cur];
+            vn = P.t_vn[cur * C.dc + trow]; lh = P.t_lh[cur * C.dc + trow]; pred = P.t_pred[cur * C.dc + trow];
+        }
         while (cur < P.M) {                                                // check nodes in dependency order (:2122)
-            const int cnp = P.t_cn[cur];
+            const int nxt = claim();                                       // the next task's descriptor travels under this visit
+            int ncnp = 0, nvn = 0, nlh = 0, npred = -1;
+            if (nxt < P.M) {
+                ncnp = P.t_cn[nxt];
+                nvn = P.t_vn[nxt * C.dc + trow]; nlh = P.t_lh[nxt * C.dc + trow]; npred = P.t_pred[nxt * C.dc + trow];
+            }
             const int cn = cnp & 0xFFFFFF;
-            const int vn = P.t_vn[cur * C.dc + trow], lh = P.t_lh[cur * C.dc + trow], pred = P.t_pred[cur * C.dc + trow];
             const int pp = (rl == 0 && row < C.dc) ? pred : -1;
             unsigned spins = 0;
             for (;;) {
@@ -1592,7 +1603,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
             process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cur = claim();
+            cur = nxt; cnp = ncnp; vn = nvn; lh = nlh; pred = npred;
         }
         __syncthreads();
         if (tid == 0) *next_task = 0;
