@@ -1401,6 +1401,11 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     float *const f_hint = P.v2_hint + (size_t)f * P.E;
     float *drow = dense + row * Q;
 
+    // the node's likelihood row is needed only by the variable-node update at the end; it is requested first so that
+    // its HBM round trip runs under the elementary steps
+    float x[G::EPL];
+    load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q, rl, x);
+
     // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
     EmsEntry *inl = lists + t * nmp;
     for (int k = rl; k < nmp; k += LPE) {
@@ -1453,8 +1458,6 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     }
 
     // ---- DataPassLog (:1513-1545) for my edge's variable node; result goes to its OTHER edge (:2159-2162) ----
-    float x[G::EPL];
-    load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q, rl, x);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) x[e] = x[e] - C.offset;                 // :1524
     store_row<Q, LPE>(drow, rl, x);
