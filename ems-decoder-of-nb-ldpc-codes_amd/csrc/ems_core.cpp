@@ -190,6 +190,8 @@ struct ems_handle {
     DevBuf<unsigned long long> d_stamps;
     // v2 flavour (allocated on first ems_v2_load_likelihood)
     std::vector<int> v2_t_dst, v2_vn_edge;
+    std::vector<uint8_t> v2_t_last;
+    DevBuf<uint8_t> d_v2_t_last;
     DevBuf<int> d_v2_t_dst, d_v2_vn_edge, d_v2_stage_idx, d_v2_bad;
     DevBuf<float> d_v2_like, d_v2_vtoc, d_v2_ctov, d_v2_hint, d_v2_app, d_v2_stage_like;
     DevBuf<uint8_t> d_v2_vtoci;
@@ -348,7 +350,7 @@ void ems_destroy(ems_handle *h)
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release();
-    h->d_v2_t_dst.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
+    h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release();
     for (auto &e : h->ev)
@@ -659,17 +661,19 @@ static int v2_prepare(ems_handle *h)
     for (int v = 0; v < h->N; ++v)
         if (deg[v] != 2) return fail(EMS_EUNSUPPORTED, "v2 flavour: variable node %d has %d edges, 2 required", v, deg[v]);
     h->v2_t_dst.resize(h->E);
+    h->v2_t_last.resize(h->E);
     for (int i = 0; i < h->M; ++i) {
         const int m = h->t_cnp[i] & 0xFFFFFF;
         for (int k = 0; k < h->dc; ++k) {
             const int e = m * h->dc + k, v = h->cn_vn[e];
             const int a = h->v2_vn_edge[(size_t)v * 2], b = h->v2_vn_edge[(size_t)v * 2 + 1];
             h->v2_t_dst[(size_t)i * h->dc + k] = (a == e) ? b : a;         // the first visitor writes the second edge and vice versa
+            h->v2_t_last[(size_t)i * h->dc + k] = (e == b) ? 1 : 0;          // edges are numbered in visiting order: the higher one comes last
         }
     }
     const size_t B = (size_t)h->max_batch, nm = (size_t)h->nm_alloc;
     int r;
-    if ((r = h->d_v2_t_dst.upload(h->v2_t_dst)) || (r = h->d_v2_vn_edge.upload(h->v2_vn_edge)) || (r = h->d_v2_like.alloc(B * h->N * h->q)) ||
+    if ((r = h->d_v2_t_dst.upload(h->v2_t_dst)) || (r = h->d_v2_t_last.upload(h->v2_t_last)) || (r = h->d_v2_vn_edge.upload(h->v2_vn_edge)) || (r = h->d_v2_like.alloc(B * h->N * h->q)) ||
         (r = h->d_v2_app.alloc(B * h->N * h->q)) || (r = h->d_v2_vtoc.alloc(B * h->E * nm)) || (r = h->d_v2_ctov.alloc(B * h->E * nm)) ||
         (r = h->d_v2_vtoci.alloc(B * h->E * nm)) || (r = h->d_v2_ctovi.alloc(B * h->E * nm)) || (r = h->d_v2_hint.alloc(B * h->E)) ||
         (r = h->d_v2_stage_like.alloc(B * h->N * h->q)) || (r = h->d_v2_stage_idx.alloc(B * h->N * h->q)) || (r = h->d_v2_bad.alloc(1)))
@@ -722,7 +726,7 @@ int ems_v2_decode(ems_handle *h, int B)
     shape_for_batch(h, B, P);                                           // 4-wave workgroups, 3 frames per CU, for big batches
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
-    P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p;
+    P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(ems_launch_decode_v2(P, B, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));

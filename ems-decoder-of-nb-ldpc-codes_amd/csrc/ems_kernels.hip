@@ -1457,6 +1457,44 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
         }
     }
 
+    const int dst = P.t_dst[task * C.dc + t];
+    // ---- ComputeAPPLog + Decision (:1887-1921, :1961-1975) of my edge's variable node when this is its last visit of
+    //      the sweep: both C->V messages of the node are final then (the other one was written by the earlier visitor,
+    //      a predecessor of this task).  APP = (likelihood + TMP[first edge]) + TMP[this edge], TMP = -offset except at
+    //      the listed symbols.  The APP rows themselves are stored once, by app_decide_v2 when the decode ends. ----
+    const bool lastv = rowact && P.t_last[task * C.dc + t] != 0;
+    if (__ballot(lastv) != 0ull) {
+        float a[G::EPL], c[G::EPL];
+        fill_row<Q, LPE>(drow, rl, -C.offset);
+        wave_lds_sync();
+        for (int k = rl; k < nm; k += LPE) {
+            const int g = f_ctovi[(unsigned)(dst * nm + k)];
+            if (lastv && g >= 0) drow[g] = f_ctov[(unsigned)(dst * nm + k)];
+        }
+        wave_lds_sync();
+        load_row<Q, LPE>(drow, rl, c);
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) a[e] = x[e] + c[e];
+        wave_lds_sync();
+        fill_row<Q, LPE>(drow, rl, -C.offset);
+        wave_lds_sync();
+        for (int k = rl; k < stp; k += LPE) {
+            const EmsEntry e = ol[k];
+            drow[gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1)] = e.v;
+        }
+        wave_lds_sync();
+        load_row<Q, LPE>(drow, rl, c);
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) a[e] = -(a[e] + c[e]);          // negated: first strict maximum = first strict minimum of -APP
+        wave_lds_sync();
+        const float lv = row_minmax_f<LPE, false>(array_min_f(a));
+        unsigned lgu = 0x7FFFFFFFu;
+#pragma unroll
+        for (int e = G::EPL - 1; e >= 0; --e) lgu = (a[e] == lv) ? (unsigned)G::sym_of(e, rl) : lgu;
+        const unsigned lg = row_min_u<LPE>(lgu);
+        if (lastv && rl == 0) (P.decide + (size_t)f * P.N)[(unsigned)vn] = (uint8_t)lg;
+    }
+
     // ---- DataPassLog (:1513-1545) for my edge's variable node; result goes to its OTHER edge (:2159-2162) ----
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) x[e] = x[e] - C.offset;                 // :1524
@@ -1481,7 +1519,6 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     }
     wave_lds_sync();
     if (rowact && rl == 0) f_hint[(unsigned)edge] = T_sel;
-    const int dst = P.t_dst[task * C.dc + t];
     const float last = -inl[nm - 1].v;                                        // :1545 normalisation to the nm-th value
     for (int k = rl; k < nm; k += LPE) {
         const EmsEntry e = inl[k];
@@ -1610,13 +1647,8 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
         }
         __syncthreads();
         if (tid == 0) *next_task = 0;
-        // ---- ComputeAPPLog + Decision (:2247-2248): four variable nodes per wave at a time ----
         const int nwaves = (int)(blockDim.x >> 6);
-        for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {
-            const int n = n0 + row;
-            app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + row * Q, rl, false);
-        }
-        __syncthreads();
+        // (ComputeAPPLog + Decision ran inside the visits, by the last visitor of every variable node)
         // ---- Syndrom (:1934-1949): value of the first check with a non-zero sum ----
         for (int c = tid; c < P.M; c += blockDim.x) {
             unsigned acc = 0;

@@ -75,4 +75,5 @@ struct EmsPlan {
     float *v2_app;          // [B][N][q]  APP of the last iteration run (ComputeAPPLog)
     const int *t_dst;       // [M*dc]     per (task, edge): row-order id of the OTHER edge of its variable node (dv = 2)
     const int *vn_edge;     // [N][2]     NtoB: the two edges of a variable node in row order
+    const uint8_t *t_last;  // [M*dc]     per (task, edge): 1 when this check node is the LAST visitor of the edge's variable node in a sweep
 };
