@@ -48,10 +48,11 @@ def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):
 
 
 def algorithmic_bytes_per_frame_decode_v2(N, E, q, nm, iters):
-    """v2 flavour, per iteration: every edge reads its V->C message, its node's likelihood row, writes its C->V message
-    and the other edge's V->C message (nm (f32,u8) pairs each); ComputeAPPLog + Decision read every node's likelihood
-    row and its two C->V messages and write one decision byte."""
-    return iters * (E * (q * 4 + 3 * nm * 5) + N * (q * 4 + 2 * nm * 5 + 1))
+    """v2 flavour, per iteration: every edge reads its V->C message and its node's likelihood row (all q values feed
+    the top-nm selection), writes its C->V message and the other edge's V->C message (nm (f32,u8) pairs each); the
+    hard decision of a node needs, beyond what its last visit already holds, the node's other C->V message, and
+    writes one byte."""
+    return iters * (E * (q * 4 + 3 * nm * 5) + N * (nm * 5 + 1))
 
 
 def cpu_baseline_v2(v2, matrix, nm, nop, off, itmax, sigma, threads):
