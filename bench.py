@@ -207,7 +207,10 @@ def main():
     dist = None
     if world > 1 or os.environ.get("EMS_BENCH_FORCE_DIST"):      # the env knob rehearses the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with c_stdout_to_stderr():                  # RCCL prints its version banner on stdout when the communicator comes up
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
 
     pkg = ge.load_package()
     if a.workload == "gf256_v2":
