@@ -285,50 +285,91 @@ int ems_load_code_file(const char *path, int fmt, ems_code_desc *d)
         fclose(f);
         return fail(EMS_EIO, "%s: bad header", path);
     }
-    std::vector<int> cdeg(N), rdeg(M);
-    bool ok = true;
-    for (int n = 0; n < N && ok; ++n) ok = fscanf(f, "%d", &cdeg[n]) == 1;
-    for (int m = 0; m < M && ok; ++m) ok = fscanf(f, "%d", &rdeg[m]) == 1 && rdeg[m] > 0;
-    long E = 0;
-    for (int m = 0; m < M && ok; ++m) E += rdeg[m];
-    std::vector<int> tok;
-    if (ok) {
-        tok.resize((size_t)2 * E);
-        size_t nt = 0;
-        while (nt < tok.size() && fscanf(f, "%d", &tok[nt]) == 1) ++nt;
-        ok = nt == tok.size();
-    }
+    std::vector<int> T;                                        // every integer after the header
+    for (int x; fscanf(f, "%d", &x) == 1;) T.push_back(x);
     fclose(f);
-    if (!ok) return fail(EMS_EIO, "%s: truncated or malformed alist", path);
 
+    // Layouts 1/2 (init.c:195-227): column degrees, row degrees, then 2E tokens (UBS blocks or KN pairs).
+    // Layout 3, the full non-binary alist (matrices/KN/N64800_*.txt; neither reference loader reads it): dvmax dcmax,
+    // column degrees, row degrees, per COLUMN (row+1, exponent) pairs, per ROW (col+1, exponent) pairs.
+    std::vector<int> cdeg, rdeg, col, cf;
+    long E = 0;
+    auto degrees = [&](size_t off) {
+        if (T.size() < off + (size_t)N + M) return false;
+        cdeg.assign(T.begin() + off, T.begin() + off + N);
+        rdeg.assign(T.begin() + off + N, T.begin() + off + N + M);
+        E = 0;
+        for (int m = 0; m < M; ++m) { if (rdeg[m] <= 0) return false; E += rdeg[m]; }
+        return true;
+    };
     auto cols_ok = [&](auto colat) {
         std::vector<int> cnt(N, 0);
         for (long e = 0; e < E; ++e) {
-            int c = colat(e);
+            const int c = colat(e);
             if (c < 0 || c >= N) return false;
             ++cnt[c];
         }
         return cnt == cdeg;
     };
-    bool ubs = cols_ok([&](long e) { return tok[e]; });
-    for (long e = 0; e < E && ubs; ++e) ubs = tok[E + e] >= 1 && tok[E + e] < q;
-    bool kn = cols_ok([&](long e) { return tok[2 * e] - 1; });
-    for (long e = 0; e < E && kn; ++e) kn = tok[2 * e + 1] >= 0 && tok[2 * e + 1] <= q - 2;
-    int use = fmt;
-    if (use == 0) use = ubs ? 1 : (kn ? 2 : -1);
-    if (use != 1 && use != 2) return fail(EMS_EIO, "%s: neither the UBS nor the KN alist layout validates", path);
+    int use = -1;
+    if ((fmt == 0 || fmt == 1 || fmt == 2) && degrees(0) && T.size() >= (size_t)N + M + 2 * (size_t)E) {
+        const int *tok = T.data() + N + M;
+        bool ubs = cols_ok([&](long e) { return tok[e]; });
+        for (long e = 0; e < E && ubs; ++e) ubs = tok[E + e] >= 1 && tok[E + e] < q;
+        bool kn = cols_ok([&](long e) { return tok[2 * e] - 1; });
+        for (long e = 0; e < E && kn; ++e) kn = tok[2 * e + 1] >= 0 && tok[2 * e + 1] <= q - 2;
+        use = fmt ? fmt : (ubs ? 1 : (kn ? 2 : -1));
+        if ((use == 1 && !ubs && fmt == 0) || (use == 2 && !kn && fmt == 0)) use = -1;
+        if (use == 1 || use == 2) {
+            col.resize(E); cf.resize(E);
+            for (long e = 0; e < E; ++e) {
+                col[e] = use == 1 ? tok[e] : tok[2 * e] - 1;
+                cf[e] = use == 1 ? tok[E + e] : tok[2 * e + 1] + 1;
+            }
+        }
+    }
+    if (use < 0 && (fmt == 0 || fmt == 3) && T.size() > 2 && degrees(2) && T.size() == 2 + (size_t)N + M + 4 * (size_t)E) {
+        const int dvmax = T[0], dcmax = T[1];
+        const int *csec = T.data() + 2 + N + M, *rsec = csec + 2 * E;
+        bool ok = true;
+        long sum = 0;
+        for (int n = 0; n < N && ok; ++n) { ok = cdeg[n] >= 0 && cdeg[n] <= dvmax; sum += cdeg[n]; }
+        for (int m = 0; m < M && ok; ++m) ok = rdeg[m] <= dcmax;
+        ok = ok && sum == E && cols_ok([&](long e) { return rsec[2 * e] - 1; });
+        for (long e = 0; e < E && ok; ++e) ok = rsec[2 * e + 1] >= 0 && rsec[2 * e + 1] <= q - 2;
+        if (ok) {                                               // the column section must describe the same matrix
+            std::vector<std::pair<int, int>> byrow, bycol;       // (row * N + col, exponent)
+            long e = 0;
+            for (int m = 0; m < M; ++m)
+                for (int k = 0; k < rdeg[m]; ++k, ++e) byrow.emplace_back(m * N + rsec[2 * e] - 1, rsec[2 * e + 1]);
+            e = 0;
+            for (int n = 0; n < N && ok; ++n)
+                for (int k = 0; k < cdeg[n]; ++k, ++e) {
+                    const int r = csec[2 * e] - 1;
+                    if (r < 0 || r >= M) { ok = false; break; }
+                    bycol.emplace_back(r * N + n, csec[2 * e + 1]);
+                }
+            std::sort(byrow.begin(), byrow.end());
+            std::sort(bycol.begin(), bycol.end());
+            ok = ok && byrow == bycol;
+        }
+        if (ok) {
+            use = 3;
+            col.resize(E); cf.resize(E);
+            for (long e = 0; e < E; ++e) { col[e] = rsec[2 * e] - 1; cf[e] = rsec[2 * e + 1] + 1; }
+        }
+    }
+    if (use < 0) return fail(EMS_EIO, "%s: none of the UBS, KN and full-alist layouts validates", path);
 
     int *rd = (int *)malloc(sizeof(int) * (size_t)M);
-    int *col = (int *)malloc(sizeof(int) * (size_t)E);
-    int *cf = (int *)malloc(sizeof(int) * (size_t)E);
-    if (!rd || !col || !cf) { free(rd); free(col); free(cf); return fail(EMS_ENOMEM, "malloc"); }
+    int *pc = (int *)malloc(sizeof(int) * (size_t)E);
+    int *pf = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!rd || !pc || !pf) { free(rd); free(pc); free(pf); return fail(EMS_ENOMEM, "malloc"); }
     memcpy(rd, rdeg.data(), sizeof(int) * (size_t)M);
-    for (long e = 0; e < E; ++e) {
-        col[e] = use == 1 ? tok[e] : tok[2 * e] - 1;
-        cf[e] = use == 1 ? tok[E + e] : tok[2 * e + 1] + 1;
-    }
+    memcpy(pc, col.data(), sizeof(int) * (size_t)E);
+    memcpy(pf, cf.data(), sizeof(int) * (size_t)E);
     d->N = N; d->M = M; d->GF = q; d->logGF = ilog2(q); d->nbBranch = (int)E;
-    d->rowDegree = rd; d->col = col; d->coef = cf;
+    d->rowDegree = rd; d->col = pc; d->coef = pf;
     return EMS_OK;
 }
 

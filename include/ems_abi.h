@@ -52,7 +52,9 @@ typedef struct {
 typedef struct ems_handle ems_handle;
 
 /* Loader that accepts BOTH on-disk layouts the reference needs a recompile for (init.c:25):
- * fmt 0 = auto-detect, 1 = "UBS" block layout (init.c:195-207), 2 = "KN" interleaved (init.c:211-227).
+ * fmt 0 = auto-detect, 1 = "UBS" block layout (init.c:195-207), 2 = "KN" interleaved (init.c:211-227), 3 = the full
+ * non-binary alist (dvmax dcmax / degrees / per-column (row+1, exponent) / per-row (col+1, exponent) pairs) of
+ * matrices/KN/N64800_*.txt, which neither loader of the reference reads.
  * Arrays are malloc()ed into *desc; release with ems_free_code_desc. */
 int ems_load_code_file(const char *path, int fmt, ems_code_desc *desc);
 void ems_free_code_desc(ems_code_desc *desc);

@@ -87,6 +87,59 @@ static int columns_match(const int *cols, int E, int N, const int *col_deg)
     return ok;
 }
 
+/* Full non-binary alist (matrices/KN/N64800_*.txt): "N M q", "dvmax dcmax", N column degrees, M row degrees, then per
+ * COLUMN its (row+1, exponent) pairs and per ROW its (col+1, exponent) pairs.  Neither loader of the reference reads it
+ * (SURVEY.md 8(f) f4); there is therefore no reference behaviour to follow, only the format: the row section is used,
+ * the column section must describe the same matrix. */
+static orc_code *load_full_alist(const int *T, size_t nT, int N, int M, int q)
+{
+    if (nT < (size_t)2 + N + M) return NULL;
+    const int dvmax = T[0], dcmax = T[1];
+    const int *cdeg = T + 2, *rdeg = T + 2 + N;
+    long E = 0, sumc = 0;
+    for (int m = 0; m < M; m++) { if (rdeg[m] <= 0 || rdeg[m] > dcmax) return NULL; E += rdeg[m]; }
+    for (int n = 0; n < N; n++) { if (cdeg[n] < 0 || cdeg[n] > dvmax) return NULL; sumc += cdeg[n]; }
+    if (sumc != E || nT != (size_t)2 + N + M + 4 * (size_t)E) return NULL;
+    const int *csec = T + 2 + N + M, *rsec = csec + 2 * E;
+    orc_code *c = calloc(1, sizeof *c);
+    c->N = N; c->M = M; c->q = q;
+    c->logq = (int)rint(log((double)q) / log(2.0));
+    c->K = N - M;
+    c->rate = (float)(N - M) / N;
+    c->col_deg = calloc((size_t)N, sizeof(int));
+    c->row_deg = calloc((size_t)M, sizeof(int));
+    c->row_ptr = calloc((size_t)M + 1, sizeof(int));
+    c->col = malloc(sizeof(int) * (size_t)E);
+    c->coef = malloc(sizeof(int) * (size_t)E);
+    c->E = (int)E;
+    int ok = 1;
+    for (int m = 0; m < M; m++) {
+        c->row_deg[m] = rdeg[m];
+        c->row_ptr[m + 1] = c->row_ptr[m] + rdeg[m];
+        if (rdeg[m] > c->dc_max) c->dc_max = rdeg[m];
+    }
+    for (long e = 0; e < E && ok; e++) {
+        c->col[e] = rsec[2 * e] - 1;
+        c->coef[e] = rsec[2 * e + 1] + 1;
+        if (c->col[e] < 0 || c->col[e] >= N || rsec[2 * e + 1] < 0 || rsec[2 * e + 1] > q - 2) ok = 0;
+        else c->col_deg[c->col[e]]++;
+    }
+    for (int n = 0; n < N && ok; n++) ok = c->col_deg[n] == cdeg[n];
+    /* cross-check with the column section: walk the columns, every (row, exponent) must be found in that row */
+    long e = 0;
+    for (int n = 0; n < N && ok; n++)
+        for (int k = 0; k < cdeg[n] && ok; k++, e++) {
+            const int r = csec[2 * e] - 1;
+            int found = 0;
+            if (r >= 0 && r < M)
+                for (int j = c->row_ptr[r]; j < c->row_ptr[r + 1]; j++)
+                    if (c->col[j] == n && c->coef[j] == csec[2 * e + 1] + 1) found = 1;
+            ok = found;
+        }
+    if (!ok) { orc_free_code(c); return NULL; }
+    return c;
+}
+
 orc_code *orc_load_code(const char *path, int fmt)
 {
     FILE *f = fopen(path, "r");
@@ -97,53 +150,61 @@ orc_code *orc_load_code(const char *path, int fmt)
         free(c);
         return NULL;
     }
+    /* every integer after the header */
+    size_t cap = 1 << 16, nT = 0;
+    int *T = malloc(cap * sizeof(int)), x;
+    while (fscanf(f, "%d", &x) == 1) {
+        if (nT == cap) { cap *= 2; T = realloc(T, cap * sizeof(int)); }
+        T[nT++] = x;
+    }
+    fclose(f);
     c->logq = (int)rint(log((double)c->q) / log(2.0)); /* init.c:163-166 */
     c->K = c->N - c->M;
     c->rate = (float)(c->N - c->M) / c->N;              /* init.c:170 */
     c->col_deg = calloc((size_t)c->N, sizeof(int));
     c->row_deg = calloc((size_t)c->M, sizeof(int));
     c->row_ptr = calloc((size_t)c->M + 1, sizeof(int));
-    int ok = 1;
-    for (int n = 0; n < c->N && ok; n++) ok = fscanf(f, "%d", &c->col_deg[n]) == 1;
-    for (int m = 0; m < c->M && ok; m++) ok = fscanf(f, "%d", &c->row_deg[m]) == 1;
-    for (int m = 0; m < c->M; m++) {
+    int ok = nT >= (size_t)c->N + c->M;
+    for (int n = 0; n < c->N && ok; n++) c->col_deg[n] = T[n];
+    for (int m = 0; m < c->M && ok; m++) c->row_deg[m] = T[c->N + m];
+    for (int m = 0; m < c->M && ok; m++) {
+        if (c->row_deg[m] <= 0) { ok = 0; break; }
         c->row_ptr[m + 1] = c->row_ptr[m] + c->row_deg[m];
         if (c->row_deg[m] > c->dc_max) c->dc_max = c->row_deg[m];
     }
-    c->E = c->row_ptr[c->M];
+    c->E = ok ? c->row_ptr[c->M] : 0;
     int E = c->E;
-    int *tok = malloc(sizeof(int) * 2 * (size_t)E);
-    int nt = 0;
-    while (ok && nt < 2 * E && fscanf(f, "%d", &tok[nt]) == 1) nt++;
-    fclose(f);
-    if (!ok || nt < 2 * E) { free(tok); orc_free_code(c); return NULL; }
-
-    c->col = malloc(sizeof(int) * (size_t)E);
-    c->coef = malloc(sizeof(int) * (size_t)E);
-    /* UBS block layout (init.c:195-207): E column indices (0-based) then E coefficients (symbol idx) */
-    int ubs_ok = columns_match(tok, E, c->N, c->col_deg);
-    for (int e = 0; e < E && ubs_ok; e++)
-        if (tok[E + e] < 1 || tok[E + e] >= c->q) ubs_ok = 0;
-    /* KN interleaved layout (init.c:211-227): (col+1, exponent) pairs */
-    int kn_ok = 1;
-    for (int e = 0; e < E; e++) {
-        c->col[e] = tok[2 * e] - 1;
-        if (tok[2 * e + 1] < 0 || tok[2 * e + 1] > c->q - 2) kn_ok = 0;
+    ok = ok && nT >= (size_t)c->N + c->M + 2 * (size_t)E;
+    const int *tok = T + c->N + c->M;
+    int use = -1;
+    if (ok && fmt != ORC_FMT_FULL) {
+        c->col = malloc(sizeof(int) * (size_t)E);
+        c->coef = malloc(sizeof(int) * (size_t)E);
+        /* UBS block layout (init.c:195-207): E column indices (0-based) then E coefficients (symbol idx) */
+        int ubs_ok = columns_match(tok, E, c->N, c->col_deg);
+        for (int e = 0; e < E && ubs_ok; e++)
+            if (tok[E + e] < 1 || tok[E + e] >= c->q) ubs_ok = 0;
+        /* KN interleaved layout (init.c:211-227): (col+1, exponent) pairs */
+        int kn_ok = 1;
+        for (int e = 0; e < E; e++) {
+            c->col[e] = tok[2 * e] - 1;
+            if (tok[2 * e + 1] < 0 || tok[2 * e + 1] > c->q - 2) kn_ok = 0;
+        }
+        kn_ok = kn_ok && columns_match(c->col, E, c->N, c->col_deg);
+        use = fmt;
+        if (use == ORC_FMT_AUTO) use = ubs_ok ? ORC_FMT_UBS : (kn_ok ? ORC_FMT_KN : -1);
+        if (use == ORC_FMT_UBS) {
+            for (int e = 0; e < E; e++) { c->col[e] = tok[e]; c->coef[e] = tok[E + e]; }
+        } else if (use == ORC_FMT_KN) {
+            for (int e = 0; e < E; e++) { c->col[e] = tok[2 * e] - 1; c->coef[e] = tok[2 * e + 1] + 1; }
+        }
     }
-    kn_ok = kn_ok && columns_match(c->col, E, c->N, c->col_deg);
-
-    int use = fmt;
-    if (use == ORC_FMT_AUTO) use = ubs_ok ? ORC_FMT_UBS : (kn_ok ? ORC_FMT_KN : -1);
-    if (use == ORC_FMT_UBS) {
-        for (int e = 0; e < E; e++) { c->col[e] = tok[e]; c->coef[e] = tok[E + e]; }
-    } else if (use == ORC_FMT_KN) {
-        for (int e = 0; e < E; e++) { c->col[e] = tok[2 * e] - 1; c->coef[e] = tok[2 * e + 1] + 1; }
-    } else {
-        free(tok);
+    if (use != ORC_FMT_UBS && use != ORC_FMT_KN) {
+        const int N = c->N, M = c->M, q = c->q;
         orc_free_code(c);
-        return NULL;
+        c = (fmt == ORC_FMT_AUTO || fmt == ORC_FMT_FULL) ? load_full_alist(T, nT, N, M, q) : NULL;
     }
-    free(tok);
+    free(T);
     return c;
 }
 

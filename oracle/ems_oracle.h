@@ -46,7 +46,7 @@ typedef struct {
     int *coef;         /* [E]   matValue[m][k] (symbol index 1..q-1)                            */
 } orc_code;
 
-enum { ORC_FMT_AUTO = 0, ORC_FMT_UBS = 1, ORC_FMT_KN = 2 };
+enum { ORC_FMT_AUTO = 0, ORC_FMT_UBS = 1, ORC_FMT_KN = 2, ORC_FMT_FULL = 3 };
 orc_code *orc_load_code(const char *path, int fmt); /* NULL on failure */
 void orc_free_code(orc_code *c);
 

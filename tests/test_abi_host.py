@@ -179,6 +179,35 @@ def test_threaded_frame_generation_equals_reference_call_sequence(harness, mat, 
     par.close()
 
 
+def test_full_alist_layout(pkg, orc, tmp_path):
+    """the full non-binary alist of matrices/KN/N64800_*.txt (dvmax dcmax line, per-column AND per-row
+    sections), which neither loader of the reference reads.  Product loader == oracle loader == an independent parse
+    of the row section; a file whose column section contradicts its row section is rejected by both."""
+    path = os.path.join(MAT, "KN_N64800_K48600_GF256_fullalist.txt")
+    tok = np.array(open(path).read().split(), np.int64)
+    N, M, q = (int(x) for x in tok[:3])
+    cdeg, rdeg = tok[5:5 + N], tok[5 + N:5 + N + M]
+    E = int(rdeg.sum())
+    assert tok[3] == cdeg.max() and tok[4] == rdeg.max() and len(tok) == 5 + N + M + 4 * E
+    rsec = tok[5 + N + M + 2 * E:].reshape(E, 2)
+    o = orc.Oracle(path)
+    assert (o.N, o.M, o.q, o.E, o.dc) == (N, M, q, E, 8)
+    assert (o.col == rsec[:, 0] - 1).all() and (o.coef == rsec[:, 1] + 1).all() and (o.row_deg == rdeg).all()
+    c = pkg.Code(path)
+    d = c.desc
+    assert (d.N, d.M, d.GF, d.nbBranch) == (N, M, q, E)
+    assert (np.ctypeslib.as_array(d.col, (E,)) == o.col).all() and (np.ctypeslib.as_array(d.coef, (E,)) == o.coef).all()
+    assert (np.ctypeslib.as_array(d.rowDegree, (M,)) == rdeg).all()
+    bad = tok.copy()
+    bad[5 + N + M + 1] += 1                                  # first exponent of the column section
+    p2 = tmp_path / "bad_alist.txt"
+    p2.write_text(" ".join(str(int(x)) for x in bad))
+    with pytest.raises(IOError):
+        orc.Oracle(str(p2))
+    with pytest.raises(pkg.EmsError):
+        pkg.Code(str(p2))
+
+
 def test_compute_entry_points_fail_loudly_without_gpu(pkg):
     """No CPU fallback: on a box without a HIP device every compute call reports EMS_ENODEV."""
     c = pkg.Code(os.path.join(MAT, "N96_K48_GF64"))

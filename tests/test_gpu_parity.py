@@ -147,6 +147,11 @@ def test_decode_gf256_dc8_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF256", 20, 40, 0.3, 12, 3.2, 1, state=True)
 
 
+def test_decode_full_alist_code_vs_oracle(pkg, orc):
+    """A code that only exists in the full-alist layout (rate 3/4, GF(256), dc = 8): loader + generic dc <= 8 kernel."""
+    _decode_vs_oracle(pkg, orc, "KN_N64800_K48600_GF256_fullalist.txt", 20, 40, 0.3, 8, 3.4, 1, state=True)
+
+
 def test_unsupported_configurations_fail_loudly(pkg):
     code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
     with pytest.raises(pkg.EmsError) as e:
