@@ -143,6 +143,23 @@ def test_decode_generic_kernels_other_degrees(pkg, orc):
     _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 20, 22, 0.3, 15, 2.5, 8)     # NbOper < nm + 3: generic kernel
 
 
+def test_decode_random_parameter_sweep(pkg, orc):
+    """Seeded random (nm, NbOper, offset, NbIterMax, Eb/N0, early exit) over the small codes of every kernel family:
+    whole-frame state against the oracle each time (fast paths, literal fallbacks, short lists, early stops)."""
+    rs = np.random.RandomState(2026)
+    codes = [("N96_K48_GF64", 64), ("Mat24_N192_M96", 64), ("Mat26_N48_M16", 64), ("Mat28_N72_M18", 64), ("Mat212_N96_M16", 64),
+             ("KN_N128_K64_GF256.txt", 256), ("KN_N576_K480_GF64.txt", 64)]
+    for trial in range(28):
+        name, q = codes[trial % len(codes)]
+        nm = int(rs.choice([5, 6, 8, 12, 16, 20, 24, 30, 32]))
+        nm = min(nm, q)
+        nop = int(rs.choice([max(1, nm - 2), nm, nm + 1, nm + 3, 2 * nm, 3 * nm, 70]))
+        off = float(rs.choice([0.0, 0.3, 0.5, 1.0]))
+        itmax = int(rs.randint(2, 9))
+        ebn = float(rs.choice([-1.0, 1.0, 2.5, 4.0, 6.0]))
+        _decode_vs_oracle(pkg, orc, name, nm, nop, off, itmax, ebn, 3, state=True, early_exit=bool(trial % 3))
+
+
 def test_decode_gf256_dc8_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF256", 20, 40, 0.3, 12, 3.2, 1, state=True)
 
