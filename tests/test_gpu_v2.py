@@ -53,6 +53,20 @@ def test_v2_small_code_other_parameters(pkg, v2):
     _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 5, 6, 0.5, 6, [(0.9, 17), (1.1, 18)])         # NbOper < nm + 3
 
 
+def test_v2_random_parameter_sweep(pkg, v2):
+    """Seeded random (nm, NbOper, offset, NbIterMax, noise, early exit) on the small dc = 4, dv = 2 codes."""
+    rs = np.random.RandomState(77)
+    codes = [("N96_K48_GF64", 64, 6), ("KN_N128_K64_GF256.txt", 256, 8), ("Mat24_N192_M96", 64, 6)]
+    for trial in range(24):
+        name, q, lq = codes[trial % len(codes)]
+        nm = int(rs.choice([5, 6, 8, 12, 16, 20, 24, 32]))
+        nop = int(rs.choice([max(2, nm - 2), nm, nm + 3, 2 * nm, 3 * nm, 70]))
+        off = float(rs.choice([0.0, 0.3, 0.5, 1.0]))
+        itmax = int(rs.randint(2, 8))
+        cases = [(float(rs.choice([0.6, 0.8, 1.0, 1.3])), int(rs.randint(1, 10 ** 6))) for _ in range(2)]
+        _check_frames(pkg, v2, name, q, lq, nm, nop, off, itmax, cases, early_exit=bool(trial % 3))
+
+
 def test_v2_big_code_vs_oracle(pkg, v2):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
 
