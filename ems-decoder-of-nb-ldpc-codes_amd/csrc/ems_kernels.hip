@@ -1381,12 +1381,11 @@ __device__ __forceinline__ void es_stage_fast_v2(EmsEntry *lists, int *lens, uns
     if (has && p16 == 0) lens[o_id] = S;
 }
 
-template <int Q>
+template <int Q, int LPE>
 __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, int f, int cn, int task, int vn, int lh,
                                               const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
                                               EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane)
 {
-    constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     const int rl = lane & (LPE - 1), row = lane / LPE;
     const bool rowact = row < C.dc;
@@ -1570,10 +1569,9 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     if (active && rl == 0) (P.decide + (size_t)f * P.N)[n] = (uint8_t)lg;
 }
 
-template <int Q, int NM = 0, bool OCC4 = false>
+template <int Q, int LPE = 16, int NM = 0, bool OCC4 = false>
 __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(const EmsPlan P)
 {
-    constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     Cfg C;
     C.dc = P.dc; C.nm = NM > 0 ? NM : P.nm; C.nbOper = P.nbOper; C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);   // (NM > 0: nbOper >= NM + 3)
@@ -1640,7 +1638,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
             case 1: __builtin_amdgcn_s_setprio(1); break;
             default: __builtin_amdgcn_s_setprio(0); break;
             }
-            process_cn_v2<Q>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane);
+            process_cn_v2<Q, LPE>(P, C, f, cn, cur, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             cur = nxt; cnp = ncnp; vn = nvn; lh = nlh; pred = npred;
@@ -1666,9 +1664,9 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
         synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
         it = sweep + 1;
         if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
-            for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {
-                const int n = n0 + row;
-                app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + row * Q, rl, true);
+            for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {          // (rows of 16 lanes here, whatever LPE is)
+                const int n = n0 + (lane >> 4);
+                app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + (lane >> 4) * Q, lane & 15, true);
             }
         }
         if ((synd == 0 && P.early_exit)) break;
@@ -2058,23 +2056,26 @@ hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int
     hipLaunchKernelGGL(k_v2_init, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, like, like_idx, N, q, nm, E, vn_edge, likeS, vtoc, vtoci, hint, bad);
     return hipGetLastError();
 }
-hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st)
+template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launch_decode_v2_t(const EmsPlan &P, int B, hipStream_t st)
 {
-    if (ems_lpe_for(P.dc) != 16 || P.dc < 2) return hipErrorInvalidValue;
-    const size_t lds = ems_wg_lds_bytes(P.q, P.M, P.wave_lds_bytes, P.waves_per_wg);
-    hipError_t e;
-    if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && P.occ4 && P.waves_per_wg <= 4) {   // 4 frames per CU
-        if ((e = set_max_lds(k_decode_v2<256, 20, true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_decode_v2<256, 20, true>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
-    } else if (P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64) {       // the BASELINE message size, compile-time
-        if ((e = set_max_lds(k_decode_v2<256, 20>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_decode_v2<256, 20>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
-    } else if (P.q == 256) {
-        if ((e = set_max_lds(k_decode_v2<256>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_decode_v2<256>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
-    } else if (P.q == 64) {
-        if ((e = set_max_lds(k_decode_v2<64>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_decode_v2<64>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
-    } else return hipErrorInvalidValue;
+    const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_v2<Q, LPE, NM, OCC4>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_v2<Q, LPE, NM, OCC4>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
+}
+hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
+{
+    const int lpe = ems_lpe_for(P0.dc);
+    if ((lpe != 16 && lpe != 8) || P0.dc < 2) return hipErrorInvalidValue;
+    EmsPlan P = P0;
+    if (P.waves_per_wg > 12) P.waves_per_wg = 12;              // the kernel's launch bound
+    const bool base = P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && lpe == 16;   // the BASELINE message size, compile-time
+    if (base && P.occ4 && P.waves_per_wg <= 4) return launch_decode_v2_t<256, 16, 20, true>(P, B, st);   // 4 frames per CU
+    if (base) return launch_decode_v2_t<256, 16, 20>(P, B, st);
+    if (P.q == 256 && lpe == 16) return launch_decode_v2_t<256, 16>(P, B, st);
+    if (P.q == 256 && lpe == 8) return launch_decode_v2_t<256, 8>(P, B, st);
+    if (P.q == 64 && lpe == 16) return launch_decode_v2_t<64, 16>(P, B, st);
+    if (P.q == 64 && lpe == 8) return launch_decode_v2_t<64, 8>(P, B, st);
+    return hipErrorInvalidValue;
 }

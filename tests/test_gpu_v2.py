@@ -67,6 +67,14 @@ def test_v2_random_parameter_sweep(pkg, v2):
         _check_frames(pkg, v2, name, q, lq, nm, nop, off, itmax, cases, early_exit=bool(trial % 3))
 
 
+def test_v2_check_degree_8(pkg, v2):
+    """dc = 8 (rows of 8 lanes): GF(256) rate 3/4 (UBS and full-alist files), GF(64) small code."""
+    _check_frames(pkg, v2, "Ahmed_64800_R34_GF256", 256, 8, 20, 40, 0.3, 6, [(0.5, 21), (0.62, 22)])
+    _check_frames(pkg, v2, "KN_N64800_K48600_GF256_fullalist.txt", 256, 8, 16, 32, 0.5, 4, [(0.55, 23)])
+    _check_frames(pkg, v2, "Mat28_N72_M18", 64, 6, 12, 24, 0.3, 8, [(0.6, 24), (0.9, 25), (1.2, 26)])
+    _check_frames(pkg, v2, "Mat26_N48_M16", 64, 6, 10, 30, 0.3, 8, [(0.7, 27), (1.0, 28)])          # dc = 6
+
+
 def test_v2_big_code_vs_oracle(pkg, v2):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
 

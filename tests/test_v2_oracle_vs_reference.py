@@ -138,6 +138,25 @@ def test_frame_decode_reference_channel(v2, ref256):
         assert a[k].tobytes() == b[k].tobytes(), k
 
 
+def test_frame_decode_check_degree_8(v2):
+    """Rate 3/4 GF(256) code (dc = 8): twelve elementary steps per check node instead of six."""
+    if not os.path.exists(v2.REF_V2):
+        pytest.skip("oracle/_ref/libref_v2.so not built")
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF256")
+    o = v2.V2Oracle(path)
+    with quiet():
+        r = v2.RefV2(path, 20)
+    for sigma, seed in ((0.5, 21), (0.62, 22)):
+        like, idx = v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, sigma, seed)
+        a = o.decode(like, idx, 20, 40, 0.3, 6)
+        with quiet():
+            b = r.decode(like, idx, 40, 0.3, 6)
+        assert a["iters"] == b["iters"] and a["synd"] == b["synd"] and (a["decide"] == b["decide"]).all()
+        for k in ("vtoc", "vtoci", "ctov", "ctovi", "app"):
+            assert a[k].tobytes() == b[k].tobytes(), (seed, k)
+    r.close()
+
+
 def test_frame_decode_gf64_with_supplied_tables(v2):
     """The core functions are field-agnostic given the tables (the reference fills BINGF for GF(256) only,
     v2.c:972-978): GF(64) N=96 code, other nm / NbOper / offset."""
