@@ -35,7 +35,7 @@ WORKLOADS = {
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
     # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
-    # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (oracle/orc_v2.synthetic_likelihood, sigma 0.95)
+    # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (synthetic_likelihood below, sigma 0.95)
     "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1024),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -67,20 +67,30 @@ def cpu_baseline_v2(v2, matrix, nm, nop, off, itmax, sigma, threads):
             "sample": "%d frames (1 per thread), v2 oracle, fixed work %d iterations, %.1f s wall" % (threads, itmax + 1, dt)}
 
 
+def synthetic_likelihood(N, q, logq, idx2bin, sigma, seed):
+    """Bench input generator for the v2 flavour (the product path never touches oracle/): max-is-best log-likelihoods
+    of an all-zero BPSK codeword over AWGN, per node the q values in decreasing order with their symbols -- the layout
+    of decoder.likelihood / likelihood_index (v2.c:1483-1497)."""
+    rs = np.random.RandomState(seed)
+    y = (1.0 + sigma * rs.randn(N, logq)).astype(np.float32)
+    bits = ((idx2bin.astype(np.int64)[:, None] >> np.arange(logq)[None, :]) & 1).astype(np.float32)
+    d = (y[:, None, :] - (1.0 - 2.0 * bits)[None, :, :]) ** 2
+    llr = (-d.sum(axis=2) / np.float32(2.0 * sigma * sigma)).astype(np.float32)
+    order = np.argsort(-llr, axis=1, kind="stable")
+    return np.ascontiguousarray(np.take_along_axis(llr, order, axis=1), np.float32), np.ascontiguousarray(order.astype(np.int32))
+
+
 def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
-    """The v2 flavour's line: same contract, the step is init-from-staged-likelihoods + k_decode_v2 + results."""
-    import importlib as il
-    orc = ge.load_oracle()
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    v2 = il.import_module("orc_v2")
+    """The v2 flavour's line: same contract, the step is init-from-staged-likelihoods + k_decode_v2 + results.
+    (oracle/ is imported only by the cpu_baseline leg.)"""
     mat, nm, nop, off, itmax, _e, B0 = WORKLOADS["gf256_v2"]
     B = a.batch or B0
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)
-    o = v2.V2Oracle(matrix)
+    idx2bin, _b2i = pkg.gf_tables(code.GF)
     sigma = 0.95
     t_setup = time.time()
-    base = [v2.synthetic_likelihood(o.N, o.q, o.logq, o.o.idx2bin, sigma, 1000 * rank + s) for s in range(8)]
+    base = [synthetic_likelihood(code.N, code.GF, code.logGF, idx2bin, sigma, 1000 * rank + s) for s in range(8)]
     like = np.stack([base[i % 8][0] for i in range(B)])
     idx = np.stack([base[i % 8][1] for i in range(B)])
     t_setup = time.time() - t_setup
@@ -138,7 +148,11 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
             except Exception:
                 pass
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_v2(v2, matrix, nm, nop, off, itmax, sigma, max(1, min(os.cpu_count() or 1, 16)))
+            import importlib as il
+            ge.load_oracle()
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            out["cpu_baseline"] = cpu_baseline_v2(il.import_module("orc_v2"), matrix, nm, nop, off, itmax, sigma,
+                                                   max(1, min(os.cpu_count() or 1, 16)))
         print(json.dumps(out), flush=True)
     dec.close()
     if dist is not None:
