@@ -3,15 +3,15 @@ import os, sys, importlib, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
-pkg = ge.load_package(); orc = ge.load_oracle(); orc.build()
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-v2 = importlib.import_module("orc_v2")
+pkg = ge.load_package()
+import bench
 path = os.path.join(ge.MATRICES, "Ahmed_64800_R12_GF256")
-o = v2.V2Oracle(path)
+code = pkg.Code(path)
+i2b, _ = pkg.gf_tables(256)
 for B in [int(x) for x in (sys.argv[1:] or ["256"])]:
-    base = [v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, 0.95, s) for s in range(4)]
+    base = [bench.synthetic_likelihood(code.N, 256, 8, i2b, 0.95, s) for s in range(4)]
     like = np.stack([base[i % 4][0] for i in range(B)]); idx = np.stack([base[i % 4][1] for i in range(B)])
-    dec = pkg.Decoder(pkg.Code(path), 20, 40, 0.3, 28, max_batch=B, early_exit=False)
+    dec = pkg.Decoder(code, 20, 40, 0.3, 28, max_batch=B, early_exit=False)
     ts = []
     for rep in range(3):
         dec.v2_load_likelihood(like, idx); dec.v2_decode(B); dec.synchronize(); ts.append(dec.last_decode_ms)
