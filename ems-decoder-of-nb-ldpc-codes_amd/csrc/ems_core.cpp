@@ -426,7 +426,6 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     }
     if (E != c->nbBranch) return bail(fail(EMS_EINVAL, "nbBranch does not match the row degrees"));
     if (!ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "check degree %d > 16 is not built", h->dc));
-    if (ems_lpe_for(h->dc) == 4 && h->q > 64) return bail(fail(EMS_EUNSUPPORTED, "check degree %d with GF(%d) is not built (dc > 8 needs GF <= 64)", h->dc, h->q));
     if (h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 

@@ -776,7 +776,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
     // wide rows: the survivors of a threshold are kept as a per-lane bit mask (above_mask) and compacted by walking
     // the set bits -- a lane owns EPL symbols but only one or two survive
-    constexpr bool BYMASK = (G::EPL >= 4) && (Q > SEL_CAP);
+    constexpr bool BYMASK = (G::EPL >= 4) && (G::EPL <= 32) && (Q > SEL_CAP);   // (the mask is one 32-bit word)
     unsigned am = 0u;
     // ---- A ----
     const float lmin = array_min_f(mvc);
@@ -1958,6 +1958,7 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
         if (P.q == 64) return launch_decode_t<64, 8>(P, B, st);
         if (P.q == 16) return launch_decode_t<16, 8>(P, B, st);
     } else if (lpe == 4) {
+        if (P.q == 256) return launch_decode_t<256, 4>(P, B, st);   // 64 symbols per lane: correct, register-bound (spills)
         if (P.q == 64) return launch_decode_t<64, 4>(P, B, st);
         if (P.q == 16) return launch_decode_t<16, 4>(P, B, st);
     }

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 W = {"gf256": ("Ahmed_64800_R12_GF256", 20, 40, 30, 1.0, 256), "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 30, 0.0, 256),
-     "n96": ("N96_K48_GF64", 16, 32, 30, -3.0, 8192)}
+     "n96": ("N96_K48_GF64", 16, 32, 30, -3.0, 8192), "gf256r56": ("Ahmed_64800_R56_GF256", 20, 40, 30, 3.0, 256),
+     "gf256r34": ("Ahmed_64800_R34_GF256", 20, 40, 30, 2.0, 256)}
 for w in (sys.argv[1:] or ["gf256"]):
     B = None
     if ":" in w: w, B = w.split(":"); B = int(B)

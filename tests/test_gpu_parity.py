@@ -164,6 +164,11 @@ def test_decode_gf256_dc8_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF256", 20, 40, 0.3, 12, 3.2, 1, state=True)
 
 
+def test_decode_gf256_dc12_vs_oracle(pkg, orc):
+    """Rate 5/6 GF(256) code of the reference's matrices/ (dc = 12): rows of 4 lanes with 64 symbols per lane."""
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R56_GF256", 20, 40, 0.3, 6, 4.6, 1, state=True)
+
+
 def test_decode_full_alist_code_vs_oracle(pkg, orc):
     """A code that only exists in the full-alist layout (rate 3/4, GF(256), dc = 8): loader + generic dc <= 8 kernel."""
     _decode_vs_oracle(pkg, orc, "KN_N64800_K48600_GF256_fullalist.txt", 20, 40, 0.3, 8, 3.4, 1, state=True)
