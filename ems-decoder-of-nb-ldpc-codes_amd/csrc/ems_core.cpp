@@ -688,7 +688,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P);
 static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
-    if (ems_lpe_for(h->dc) != 16 && ems_lpe_for(h->dc) != 8) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 8 is not built", h->dc);
+    if (!ems_lpe_for(h->dc)) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 16 is not built", h->dc);
     if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
     // the reference's Flag trick (v2.c:2157) needs exactly two edges per variable node
     std::vector<int> deg(h->N, 0);

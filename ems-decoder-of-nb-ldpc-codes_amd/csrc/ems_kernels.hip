@@ -2068,7 +2068,7 @@ template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launc
 hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
 {
     const int lpe = ems_lpe_for(P0.dc);
-    if ((lpe != 16 && lpe != 8) || P0.dc < 2) return hipErrorInvalidValue;
+    if ((lpe != 16 && lpe != 8 && lpe != 4) || P0.dc < 2) return hipErrorInvalidValue;
     EmsPlan P = P0;
     if (P.waves_per_wg > 12) P.waves_per_wg = 12;              // the kernel's launch bound
     const bool base = P.q == 256 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && lpe == 16;   // the BASELINE message size, compile-time
@@ -2078,5 +2078,8 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
     if (P.q == 256 && lpe == 8) return launch_decode_v2_t<256, 8>(P, B, st);
     if (P.q == 64 && lpe == 16) return launch_decode_v2_t<64, 16>(P, B, st);
     if (P.q == 64 && lpe == 8) return launch_decode_v2_t<64, 8>(P, B, st);
+    if (P.waves_per_wg > 8) P.waves_per_wg = 8;
+    if (P.q == 256 && lpe == 4) return launch_decode_v2_t<256, 4>(P, B, st);   // 64 symbols per lane: register-bound
+    if (P.q == 64 && lpe == 4) return launch_decode_v2_t<64, 4>(P, B, st);
     return hipErrorInvalidValue;
 }

@@ -106,7 +106,7 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
  * Max-is-best log-likelihoods, nm-long messages both ways, 4-candidate bubble check (v2.c:1547), horizontal
  * schedule (v2.c:2119-2253).  Same handle (ems_create: nm, NbOper, offset, NbIterMax, early_exit); the decode
  * runs iterations iter = 0..NbIterMax inclusive like the reference's loop.  Needs dv = 2 (the reference's Flag
- * trick, v2.c:2157), regular check degree <= 8, GF(64) or GF(256).
+ * trick, v2.c:2157), regular check degree <= 16, GF(64) or GF(256).
  *   like / like_idx: [B][N][GF], per node the GF likelihoods in decreasing order and their symbols, i.e.
  *   decoder.likelihood / decoder.likelihood_index as ModelChannelAWGN leaves them (v2.c:1483-1497).
  *   Results through ems_get_results (decide, iterations executed, syndrome). */

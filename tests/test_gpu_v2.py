@@ -75,6 +75,12 @@ def test_v2_check_degree_8(pkg, v2):
     _check_frames(pkg, v2, "Mat26_N48_M16", 64, 6, 10, 30, 0.3, 8, [(0.7, 27), (1.0, 28)])          # dc = 6
 
 
+def test_v2_check_degree_12(pkg, v2):
+    """dc = 12 (rows of 4 lanes): the rate-5/6 GF(256) code and a small GF(64) one."""
+    _check_frames(pkg, v2, "Ahmed_64800_R56_GF256", 256, 8, 20, 40, 0.3, 4, [(0.42, 31)])
+    _check_frames(pkg, v2, "Mat212_N96_M16", 64, 6, 12, 24, 0.3, 6, [(0.5, 32), (0.8, 33)])
+
+
 def test_v2_big_code_vs_oracle(pkg, v2):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
 
@@ -144,7 +150,7 @@ def test_v2_golden_frames_from_the_reference(pkg, orc, v2):
 
 
 def test_v2_rejects_what_it_does_not_build(pkg, v2):
-    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")            # dc = 8, GF(16)
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")            # GF(16)
     dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 5, max_batch=1)
     o = v2.V2Oracle(path)
     like, idx = v2.synthetic_likelihood(o.N, 16, 4, o.o.idx2bin, 0.8, 1)
