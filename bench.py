@@ -305,7 +305,7 @@ def main():
             src.position(1 << 20)                   # frames far from the ones of the timed run
             ocw, onoisy, osigma = src.draw(nd, OPER_EBN)
             src.close()
-        Bo = 2 * B
+        Bo = 4 * B                                  # several waves of workgroups: finished frames free their CU slots for queued ones
         reps = -(-Bo // nd)
         ocw = np.tile(ocw, (reps, 1))[:Bo]; onoisy = np.tile(onoisy, (reps, 1, 1))[:Bo]
         od = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bo, device=local, early_exit=True)
