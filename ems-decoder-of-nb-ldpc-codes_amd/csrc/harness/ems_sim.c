@@ -114,9 +114,12 @@ int main(int argc, char *argv[])
         }
     ems_code_desc desc = {code.N, code.M, code.GF, code.logGF, code.nbBranch, code.rowDegree, col, coef};
     ems_params prm = {nbMax, NbOper, offset, NbIterMax, 1};
-    ems_handle *h = NULL;
-    int rc = ems_create(&h, &desc, &prm, batch, device);
-    if (rc) die("ems_create", rc);
+    /* Two decoder handles (own streams) used alternately: batch k+1 is launched before the results of batch k
+     * are fetched, so the tail of a batch (its few frames that run every iteration) overlaps the next one. */
+    ems_handle *hd[2] = {NULL, NULL};
+    int rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = ems_create(&hd[i], &desc, &prm, batch, device))) die("ems_create", rc);
 
     char note[40] = "FB30";
     char file_name[128];
@@ -131,60 +134,78 @@ int main(int argc, char *argv[])
     for (int n = 0; n < N; n++) NBIN[n] = calloc(logGF, sizeof(int));
     for (int k = 0; k < K; k++) KBIN[k] = calloc(logGF, sizeof(int));
     int *KSYMB = calloc(K, sizeof(int));
-    int *cwbuf[2] = {malloc(sizeof(int) * (size_t)batch * N), malloc(sizeof(int) * (size_t)batch * N)};
-    float *nybuf[2] = {malloc(sizeof(float) * (size_t)batch * N * logGF), malloc(sizeof(float) * (size_t)batch * N * logGF)};
+    enum { NBUF = 3 };                                                  /* being drawn / in flight / being tallied */
+    int *cwbuf[NBUF];
+    float *nybuf[NBUF];
+    for (int i = 0; i < NBUF; i++) {
+        cwbuf[i] = malloc(sizeof(int) * (size_t)batch * N);
+        nybuf[i] = malloc(sizeof(float) * (size_t)batch * N * logGF);
+    }
     int *decide = malloc(sizeof(int) * (size_t)batch * N);
     int *iters = malloc(sizeof(int) * batch), *synd = malloc(sizeof(int) * batch), *nberr = malloc(sizeof(int) * batch);
 
     int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
     double t_decode = 0, t_gen = 0;
-    gen_job job[2];
-    for (int i = 0; i < 2; i++)
+    gen_job job[NBUF];
+    for (int i = 0; i < NBUF; i++)
         job[i] = (gen_job){&code, &table, 0, 0, threads, EbN, 0.0f, cwbuf[i], nybuf[i], NBIN, KBIN, KSYMB, &Idum, 0.0, 0};
     pthread_t producer;
-    int cur = 0, drawn = 0;                                             /* frames handed to the generator so far */
+    int drawn = 0;                                                      /* frames handed to the generator so far */
     job[0].first = 0;
     job[0].B = NbMonteCarlo < batch ? NbMonteCarlo : batch;
     drawn = job[0].B;
     generate(&job[0]);
-    while (nb < NbMonteCarlo && !stop) {
-        const int B = job[cur].B;
-        if (job[cur].rc) die("ems_draw_frames", job[cur].rc);
-        const float sigma = job[cur].sigma;
-        int *cw = job[cur].cw;
-        float *noisy = job[cur].noisy;
-        t_gen += job[cur].seconds;
-        int have_next = 0;
-        if (drawn < NbMonteCarlo) {                                     /* draw the next batch while this one decodes */
-            job[cur ^ 1].first = drawn;
-            job[cur ^ 1].B = (NbMonteCarlo - drawn) < batch ? (NbMonteCarlo - drawn) : batch;
-            drawn += job[cur ^ 1].B;
-            have_next = pthread_create(&producer, NULL, generate, &job[cur ^ 1]) == 0;
-            if (!have_next) generate(&job[cur ^ 1]);
-        }
-        struct timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        if ((rc = ems_decode_batch(h, noisy, sigma, B, decide, iters, synd))) die("ems_decode_batch", rc);
-        if ((rc = ems_count_errors(h, cw, B, nberr))) die("ems_count_errors", rc);
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        t_decode += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-        for (int b = 0; b < B; b++) {                                   /* NB_LDPC.c:474-507, frame order */
-            nb++;
-            sum_it += iters[b];
-            total_errors += nberr[b];
-            if (nberr[b] != 0) {
-                nbErroneousFrames++;
-                if (synd[b] == 0) nbUndetectedErrors++;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int launched = 0, tallied = 0;                                      /* batch counters; batch k uses job[k % NBUF], hd[k & 1] */
+    for (;;) {
+        int have_next = 0, more = 0;
+        if ((long)launched * batch < NbMonteCarlo) {
+            gen_job *j = &job[launched % NBUF];
+            if (j->rc) die("ems_draw_frames", j->rc);
+            t_gen += j->seconds;
+            if (drawn < NbMonteCarlo) {                                 /* draw the next batch while this one decodes */
+                gen_job *n = &job[(launched + 1) % NBUF];
+                n->first = drawn;
+                n->B = (NbMonteCarlo - drawn) < batch ? (NbMonteCarlo - drawn) : batch;
+                drawn += n->B;
+                have_next = pthread_create(&producer, NULL, generate, n) == 0;
+                if (!have_next) generate(n);
             }
-            printf("\r<%d> FER= %d / %d = %f BER= %d / x = %f  avr_it=%.2f", nbUndetectedErrors, nbErroneousFrames, nb,
-                   (double)nbErroneousFrames / nb, total_errors, (double)total_errors / ((double)nb * K * logGF),
-                   (double)sum_it / nb);
-            fflush(stdout);
-            if (nbErroneousFrames == 40) { stop = 1; break; }
+            ems_handle *h = hd[launched & 1];                           /* asynchronous: upload, LLR kernel, decode kernel */
+            if ((rc = ems_llr_init(h, j->noisy, j->sigma, j->B))) die("ems_llr_init", rc);
+            if ((rc = ems_decode(h, j->B))) die("ems_decode", rc);
+            launched++;
+            more = 1;
+        }
+        if (launched - tallied == 2 || (!more && launched > tallied)) { /* fetch the older batch (blocks on its stream) */
+            gen_job *j = &job[tallied % NBUF];
+            ems_handle *h = hd[tallied & 1];
+            const int B = j->B;
+            if ((rc = ems_get_results(h, B, decide, iters, synd))) die("ems_get_results", rc);
+            if ((rc = ems_count_errors(h, j->cw, B, nberr))) die("ems_count_errors", rc);
+            tallied++;
+            for (int b = 0; b < B; b++) {                               /* NB_LDPC.c:474-507, frame order */
+                nb++;
+                sum_it += iters[b];
+                total_errors += nberr[b];
+                if (nberr[b] != 0) {
+                    nbErroneousFrames++;
+                    if (synd[b] == 0) nbUndetectedErrors++;
+                }
+                printf("\r<%d> FER= %d / %d = %f BER= %d / x = %f  avr_it=%.2f", nbUndetectedErrors, nbErroneousFrames, nb,
+                       (double)nbErroneousFrames / nb, total_errors, (double)total_errors / ((double)nb * K * logGF),
+                       (double)sum_it / nb);
+                fflush(stdout);
+                if (nbErroneousFrames == 40) { stop = 1; break; }
+            }
         }
         if (have_next) pthread_join(producer, NULL);                    /* (dropped if the 40-error stop came first) */
-        cur ^= 1;
+        if (stop || (!more && launched == tallied)) break;
     }
+    for (int i = 0; i < 2; i++) ems_synchronize(hd[i]);                 /* a batch launched ahead of the stop is dropped */
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    t_decode = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
     const int nb_logged = stop ? nb : nb + 1;
     printf(" \n results are printed in file %s \n", file_name);
@@ -202,11 +223,12 @@ int main(int argc, char *argv[])
     printf(" \n results printed \n ");
     printf("\n");
     printf("Simulation complete at time: %s", ts);
-    fprintf(stderr, "[ems_sim] %d frames, GPU decode wall %.3f s (%.1f frames/s incl. PCIe), batch %d; host frame generation %.3f s on %d thread(s)\n",
+    fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; host frame generation %.3f s on %d thread(s)\n",
             nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, t_gen, threads);
 
-    ems_destroy(h);
-    free(col); free(coef); free(cwbuf[0]); free(cwbuf[1]); free(nybuf[0]); free(nybuf[1]); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
+    ems_destroy(hd[0]); ems_destroy(hd[1]);
+    for (int i = 0; i < NBUF; i++) { free(cwbuf[i]); free(nybuf[i]); }
+    free(col); free(coef); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
     for (int n = 0; n < N; n++) free(NBIN[n]);
     for (int k = 0; k < K; k++) free(KBIN[k]);
     free(NBIN); free(KBIN);

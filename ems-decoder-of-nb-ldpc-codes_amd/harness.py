@@ -130,25 +130,42 @@ def _dist():
 
 
 def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=64, device=0, decode_fn=None,
-                max_err_frames=40, tensor_device="cpu", verbose=False):
+                max_err_frames=40, tensor_device="cpu", verbose=False, inflight=2):
     """Run the Monte-Carlo loop over all ranks of the current process group (or one process).
 
     decode_fn(noisy, sigma, cws) -> (nberr[B], synd[B], iters[B]); default = the GPU decoder.  The CPU
     tests inject a stand-in so the sharding / reduction / ordering logic runs without a GPU.
+    `inflight` decoder handles (each with its own stream) are used round-robin: round r+1 is launched before
+    the results of round r are fetched, so the few frames of a round that run all iterations (its tail)
+    share the GPU with the head of the next round.  Rounds are still tallied strictly in frame order; a
+    round launched ahead of the 40-error stop is dropped, exactly like a frame drawn ahead of it.
     Returns (Counters on every rank -- identical everywhere --, number of decode rounds)."""
     import torch
     dist = _dist()
     rank = dist.get_rank() if dist else 0
     world = dist.get_world_size() if dist else 1
     src = FrameSource(matrix, nm)
-    dec = None
+    decs = []
     if decode_fn is None:
         code = Code(matrix)
-        dec = Decoder(code, nm, NbOper, offset, NbIterMax, max_batch=batch, device=device)
+        inflight = max(1, int(inflight))
+        decs = [Decoder(code, nm, NbOper, offset, NbIterMax, max_batch=batch, device=device) for _ in range(inflight)]
 
-        def decode_fn(noisy, sigma, cws):
-            _d, iters, synd = dec.decode_batch(noisy, sigma)
-            return dec.count_errors(cws), synd, iters
+        def submit(slot, noisy, sigma, cws):           # asynchronous: upload + ems_decode on the handle's stream
+            d = decs[slot]
+            B = d.llr_init(noisy, sigma)
+            d.decode(B)
+
+            def collect():
+                _d, iters, synd = d.results(B)
+                return d.count_errors(cws), synd, iters
+            return collect
+    else:
+        inflight = 1
+
+        def submit(slot, noisy, sigma, cws):
+            res = decode_fn(noisy, sigma, cws)
+            return lambda: res
 
     cnt = Counters(src.s.K, src.s.logGF)
     rounds = 0
@@ -165,15 +182,11 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(1)                        # the next round is drawn while this one decodes
     pending = pool.submit(draw_round, 0)
-    for r in range(n_rounds):
-        start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
+    def tally(r, count, collect):                       # results of round r -> counters (collective when distributed)
+        nonlocal rounds, stop
         triples = np.full((batch, 3), -1, np.int64)
-        frames = pending.result()
-        if r + 1 < n_rounds:
-            pending = pool.submit(draw_round, r + 1)
         if count > 0:
-            cws, noisy, sigma = frames
-            nberr, synd, iters = decode_fn(noisy, sigma, cws)
+            nberr, synd, iters = collect()
             triples[:count, 0], triples[:count, 1], triples[:count, 2] = nberr, synd, iters
         local = np.array([count, int((triples[:count, 0] != 0).sum()), int(triples[:count, 0].sum()),
                           int(((triples[:count, 0] != 0) & (triples[:count, 1] == 0)).sum()), int(triples[:count, 2].sum())],
@@ -185,10 +198,8 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
             gathered = [torch.empty_like(g) for _ in range(world)]
             dist.all_gather(gathered, g)                              # 12 B/frame, reporting only
             all_tr = [x.cpu().numpy() for x in gathered]
-            round_err = int(t.cpu()[1])
         else:
             all_tr = [triples]
-            round_err = int(local[1])
         rounds += 1
         for rk in range(world):                                       # global frame order
             _s, c = batch_of_rank(r, rk, world, batch, NbMonteCarlo)
@@ -198,13 +209,30 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
                     print("\r" + cnt.line(), end="", flush=True)
                 if cnt.err_frames == max_err_frames:                  # NB_LDPC.c:506
                     stop = True
-                    break
+                    return
+
+    queue = []                                          # rounds launched, not yet tallied (oldest first)
+    for r in range(n_rounds):
+        start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
+        frames = pending.result()
+        if r + 1 < n_rounds:
+            pending = pool.submit(draw_round, r + 1)
+        collect = None
+        if count > 0:
+            cws, noisy, sigma = frames
+            collect = submit(r % inflight, noisy, sigma, cws)
+        queue.append((r, count, collect))
+        if len(queue) == inflight:
+            tally(*queue.pop(0))
             if stop:
                 break
-        if stop:
-            break
+    while queue and not stop:
+        tally(*queue.pop(0))
+    for _r, _c, collect in queue:                       # launched ahead of the stop: wait, then drop
+        if collect is not None:
+            collect()
     pool.shutdown(wait=True)                            # (a round drawn ahead of the stop is simply dropped)
     src.close()
-    if dec is not None:
-        dec.close()
+    for d in decs:
+        d.close()
     return cnt, rounds
