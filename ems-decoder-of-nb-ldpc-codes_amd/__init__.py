@@ -78,6 +78,9 @@ def lib():
         L.ems_count_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ems_set_codewords.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ems_count_errors_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ems_source_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ems_source_draw.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_float]
+        L.ems_source_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ems_get_app.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_ctov.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -189,11 +192,11 @@ class Decoder:
     def decode(self, B):
         _check(lib().ems_decode(self.h, B))
 
-    def results(self, B):
-        decide = np.zeros((B, self.code.N), np.int32)
+    def results(self, B, want_decide=True):
+        decide = np.zeros((B, self.code.N), np.int32) if want_decide else None
         iters = np.zeros(B, np.int32)
         synd = np.zeros(B, np.int32)
-        _check(lib().ems_get_results(self.h, B, _ptr(decide), _ptr(iters), _ptr(synd)))
+        _check(lib().ems_get_results(self.h, B, _ptr(decide) if want_decide else None, _ptr(iters), _ptr(synd)))
         return decide, iters, synd
 
     def decode_batch(self, noisy, sigma):
@@ -238,6 +241,24 @@ class Decoder:
     def set_codewords(self, codewords):
         cw = np.ascontiguousarray(codewords, np.int32)
         _check(lib().ems_set_codewords(self.h, _ptr(cw), cw.shape[0]))
+
+    # ---- device-side frame source (include/ems_abi.h: ems_source_*) ----
+    def source_attach(self, session):
+        """`session`: a refapi.RefSession built with need_encoder=True (GaussianElimination's matUT / Perm)."""
+        c = session.code
+        if not c.matUT or not c.Perm:
+            raise ValueError("session has no encoder (need_encoder=True)")
+        _check(lib().ems_source_attach(self.h, c.matUT[0], c.Perm))
+
+    def source_draw(self, seed, first_frame, B, sigma):
+        """Frames [first_frame, first_frame+B) generated in HBM (Philox stream `seed`), LLRs initialised."""
+        _check(lib().ems_source_draw(self.h, int(seed), int(first_frame), int(B), float(sigma)))
+
+    def source_get(self, B):
+        cw = np.zeros((B, self.code.N), np.int32)
+        noisy = np.zeros((B, self.code.N, self.code.logGF), np.float32)
+        _check(lib().ems_source_get(self.h, int(B), _ptr(cw), _ptr(noisy)))
+        return cw, noisy
 
     def count_errors_resident(self, B):
         out = np.zeros(B, np.int32)

@@ -197,6 +197,11 @@ struct ems_handle {
     DevBuf<uint8_t> d_v2_vtoci;
     DevBuf<int16_t> d_v2_ctovi;
     bool v2_ready = false;
+    // device-side frame source (allocated by ems_source_attach)
+    DevBuf<int> d_src_tptr, d_src_tcol, d_src_rptr, d_src_rcol, d_src_perm;
+    DevBuf<uint8_t> d_src_tcoef, d_src_rcoef, d_src_diag, d_src_sym, d_src_rhs;
+    EmsSourcePlan src{};
+    bool src_ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_llr_ev = false, have_dec_ev = false;
@@ -388,6 +393,8 @@ void ems_destroy(ems_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
+    for (DevBuf<int> *b : {&h->d_src_tptr, &h->d_src_tcol, &h->d_src_rptr, &h->d_src_rcol, &h->d_src_perm}) b->release();
+    for (DevBuf<uint8_t> *b : {&h->d_src_tcoef, &h->d_src_rcoef, &h->d_src_diag, &h->d_src_sym, &h->d_src_rhs}) b->release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release();
@@ -619,6 +626,77 @@ int ems_set_codewords(ems_handle *h, const int *cw_host, int B)
     if (r) return r;
     if (!cw_host) return fail(EMS_EINVAL, "null argument");
     HIP_TRY(hipMemcpyAsync(h->d_cw.p, cw_host, sizeof(int) * (size_t)B * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EMS_OK;
+}
+
+// ---- device-side frame source (kernels in ems_source.hip) ----
+int ems_source_attach(ems_handle *h, const int *matUT, const int *perm)
+{
+    if (!h || !matUT || !perm) return fail(EMS_EINVAL, "null argument");
+    const int N = h->N, M = h->M;
+    std::vector<int> tptr(M + 1, 0), rptr(M + 1, 0), tcol, rcol, pv(perm, perm + N);
+    std::vector<uint8_t> tcoef, rcoef, diag(M);
+    std::vector<char> seen(N, 0);
+    for (int n = 0; n < N; ++n) {
+        if (perm[n] < 0 || perm[n] >= N || seen[perm[n]]) return fail(EMS_EINVAL, "Perm is not a permutation of 0..N-1");
+        seen[perm[n]] = 1;
+    }
+    for (int m = 0; m < M; ++m) {
+        const int *row = matUT + (size_t)m * N;
+        for (int n = 0; n < N; ++n) {
+            const int c = row[n];
+            if (c < 0 || c >= h->q) return fail(EMS_EINVAL, "matUT[%d][%d] = %d is not a GF(%d) symbol index", m, n, c, h->q);
+            if (n < m && c) return fail(EMS_EINVAL, "matUT is not upper triangular (row %d, column %d)", m, n);
+            if (n == m) {
+                if (!c) return fail(EMS_EINVAL, "matUT has a zero pivot in row %d", m);
+                diag[m] = (uint8_t)c;
+            } else if (c && n < M) {
+                tcol.push_back(n); tcoef.push_back((uint8_t)c);
+            } else if (c) {
+                rcol.push_back(n); rcoef.push_back((uint8_t)c);
+            }
+        }
+        tptr[m + 1] = (int)tcol.size();
+        rptr[m + 1] = (int)rcol.size();
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    for (DevBuf<int> *b : {&h->d_src_tptr, &h->d_src_tcol, &h->d_src_rptr, &h->d_src_rcol, &h->d_src_perm}) b->release();
+    for (DevBuf<uint8_t> *b : {&h->d_src_tcoef, &h->d_src_rcoef, &h->d_src_diag, &h->d_src_sym, &h->d_src_rhs}) b->release();
+    h->src_ready = false;
+    int r;
+    if ((r = h->d_src_tptr.upload(tptr)) || (r = h->d_src_tcol.upload(tcol)) || (r = h->d_src_tcoef.upload(tcoef)) ||
+        (r = h->d_src_rptr.upload(rptr)) || (r = h->d_src_rcol.upload(rcol)) || (r = h->d_src_rcoef.upload(rcoef)) ||
+        (r = h->d_src_diag.upload(diag)) || (r = h->d_src_perm.upload(pv)) ||
+        (r = h->d_src_sym.alloc((size_t)N * h->max_batch)) || (r = h->d_src_rhs.alloc((size_t)M * h->max_batch)))
+        return r;
+    EmsSourcePlan &S = h->src;
+    S.N = N; S.M = M; S.K = h->K; S.q = h->q; S.logq = h->logq; S.Bs = h->max_batch;
+    S.tptr = h->d_src_tptr.p; S.tcol = h->d_src_tcol.p; S.tcoef = h->d_src_tcoef.p;
+    S.rptr = h->d_src_rptr.p; S.rcol = h->d_src_rcol.p; S.rcoef = h->d_src_rcoef.p;
+    S.diag = h->d_src_diag.p; S.perm = h->d_src_perm.p; S.idx2bin = h->d_i2b.p; S.bin2idx = h->d_b2i.p;
+    S.sym = h->d_src_sym.p; S.rhs = h->d_src_rhs.p;
+    h->src_ready = true;
+    return EMS_OK;
+}
+
+int ems_source_draw(ems_handle *h, unsigned long long seed, unsigned long long first_frame, int B, float sigma)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!h->src_ready) return fail(EMS_EINVAL, "ems_source_attach has not been called on this handle");
+    if (!(sigma >= 0.f)) return fail(EMS_EINVAL, "sigma must be >= 0");
+    HIP_TRY(ems_launch_source(h->src, seed, first_frame, B, sigma, h->d_cw.p, h->d_noisy.p, h->stream));
+    return ems_llr_init_dev(h, h->d_noisy.p, sigma, B);
+}
+
+int ems_source_get(ems_handle *h, int B, int *codewords, float *noisy)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (codewords) HIP_TRY(hipMemcpyAsync(codewords, h->d_cw.p, sizeof(int) * (size_t)B * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (noisy)
+        HIP_TRY(hipMemcpyAsync(noisy, h->d_noisy.p, sizeof(float) * (size_t)B * h->N * h->logq, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return EMS_OK;
 }

@@ -31,4 +31,6 @@ hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide,
 hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
                                     const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st);
 hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_dev, int *s_gf_dev, hipStream_t st);
+hipError_t ems_launch_source(const EmsSourcePlan &S, uint64_t seed, uint64_t first_frame, int B, float sigma, int *cw_dev,
+                             float *noisy_dev, hipStream_t st);
 hipError_t ems_debug_counters(unsigned long long *out8, int reset); // diagnostic builds (-DEMS_STAMPS) only

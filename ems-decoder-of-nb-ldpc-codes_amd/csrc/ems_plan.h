@@ -77,3 +77,18 @@ struct EmsPlan {
     const int *vn_edge;     // [N][2]     NtoB: the two edges of a variable node in row order
     const uint8_t *t_last;  // [M*dc]     per (task, edge): 1 when this check node is the LAST visitor of the edge's variable node in a sweep
 };
+
+// Device-side frame source (ems_source.hip): the reference's encoder matrices in CSR.
+struct EmsSourcePlan {
+    int N, M, K, q, logq;
+    int Bs;                 // frame stride of sym / rhs (= the handle's max batch)
+    const int *tptr, *tcol; // triangular part of matUT: row m -> entries with m < col < M
+    const uint8_t *tcoef;
+    const int *rptr, *rcol; // information part: entries with col >= M
+    const uint8_t *rcoef;
+    const uint8_t *diag;    // [M] matUT[m][m]
+    const int *perm;        // [N] code_t.Perm
+    const uint8_t *idx2bin, *bin2idx;
+    uint8_t *sym;           // [N][Bs] symbols in matUT column order
+    uint8_t *rhs;           // [M][Bs] binary image of the information part's contribution to row m
+};

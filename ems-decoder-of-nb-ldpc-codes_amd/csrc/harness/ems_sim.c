@@ -8,6 +8,9 @@
  * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH) by EMS_THREADS host
  * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
+ * Two decoder handles alternate so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
+ * the frame source to the device-side counter-based generator (ems_source_draw): no host generation at all,
+ * statistical instead of bit parity with the reference's frames.
  *
  *   ems_sim NbMonteCarlo NbIterMax FileMatrix EbN NbMax Offset NbOper
  */
@@ -87,6 +90,11 @@ int main(int argc, char *argv[])
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int threads = getenv("EMS_THREADS") ? atoi(getenv("EMS_THREADS")) : (int)(ncpu > 16 ? 16 : (ncpu < 1 ? 1 : ncpu));
     if (threads < 1) threads = 1;
+    /* EMS_GPU_SOURCE=<seed>: frames are generated on the GPU from the counter-based stream <seed> (ems_source_draw:
+     * no host generation, no PCIe traffic) instead of the reference's drand48 stream -- statistical, not bit,
+     * parity with the reference's trace. */
+    const int gpu_source = getenv("EMS_GPU_SOURCE") != NULL;
+    const unsigned long long gpu_seed = gpu_source ? strtoull(getenv("EMS_GPU_SOURCE"), NULL, 0) : 0ULL;
     int Idum = -1;
 
     printf(" Monte-Carlo simulation of Non-Binary LDPC decoder \n\n");
@@ -120,6 +128,10 @@ int main(int argc, char *argv[])
     int rc;
     for (int i = 0; i < 2; i++)
         if ((rc = ems_create(&hd[i], &desc, &prm, batch, device))) die("ems_create", rc);
+    if (gpu_source)
+        for (int i = 0; i < 2; i++)
+            if ((rc = ems_source_attach(hd[i], code.matUT[0], code.Perm))) die("ems_source_attach", rc);
+    const float sigma_dev = (float)sqrt(1.0 / (2.0 * (double)code.rate * pow(10.0, (double)EbN / 10.0)));   /* channel.c:51 */
 
     char note[40] = "FB30";
     char file_name[128];
@@ -141,7 +153,6 @@ int main(int argc, char *argv[])
         cwbuf[i] = malloc(sizeof(int) * (size_t)batch * N);
         nybuf[i] = malloc(sizeof(float) * (size_t)batch * N * logGF);
     }
-    int *decide = malloc(sizeof(int) * (size_t)batch * N);
     int *iters = malloc(sizeof(int) * batch), *synd = malloc(sizeof(int) * batch), *nberr = malloc(sizeof(int) * batch);
 
     int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
@@ -154,7 +165,7 @@ int main(int argc, char *argv[])
     job[0].first = 0;
     job[0].B = NbMonteCarlo < batch ? NbMonteCarlo : batch;
     drawn = job[0].B;
-    generate(&job[0]);
+    if (!gpu_source) generate(&job[0]);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     int launched = 0, tallied = 0;                                      /* batch counters; batch k uses job[k % NBUF], hd[k & 1] */
@@ -162,9 +173,13 @@ int main(int argc, char *argv[])
         int have_next = 0, more = 0;
         if ((long)launched * batch < NbMonteCarlo) {
             gen_job *j = &job[launched % NBUF];
+            if (gpu_source) {
+                j->first = launched * batch;
+                j->B = (NbMonteCarlo - j->first) < batch ? (int)(NbMonteCarlo - j->first) : batch;
+            }
             if (j->rc) die("ems_draw_frames", j->rc);
             t_gen += j->seconds;
-            if (drawn < NbMonteCarlo) {                                 /* draw the next batch while this one decodes */
+            if (!gpu_source && drawn < NbMonteCarlo) {                  /* draw the next batch while this one decodes */
                 gen_job *n = &job[(launched + 1) % NBUF];
                 n->first = drawn;
                 n->B = (NbMonteCarlo - drawn) < batch ? (NbMonteCarlo - drawn) : batch;
@@ -173,7 +188,9 @@ int main(int argc, char *argv[])
                 if (!have_next) generate(n);
             }
             ems_handle *h = hd[launched & 1];                           /* asynchronous: upload, LLR kernel, decode kernel */
-            if ((rc = ems_llr_init(h, j->noisy, j->sigma, j->B))) die("ems_llr_init", rc);
+            if (gpu_source) {
+                if ((rc = ems_source_draw(h, gpu_seed, (unsigned long long)j->first, j->B, sigma_dev))) die("ems_source_draw", rc);
+            } else if ((rc = ems_llr_init(h, j->noisy, j->sigma, j->B))) die("ems_llr_init", rc);
             if ((rc = ems_decode(h, j->B))) die("ems_decode", rc);
             launched++;
             more = 1;
@@ -182,8 +199,8 @@ int main(int argc, char *argv[])
             gen_job *j = &job[tallied % NBUF];
             ems_handle *h = hd[tallied & 1];
             const int B = j->B;
-            if ((rc = ems_get_results(h, B, decide, iters, synd))) die("ems_get_results", rc);
-            if ((rc = ems_count_errors(h, j->cw, B, nberr))) die("ems_count_errors", rc);
+            if ((rc = ems_get_results(h, B, NULL, iters, synd))) die("ems_get_results", rc);   /* decisions stay in HBM */
+            if ((rc = gpu_source ? ems_count_errors_resident(h, B, nberr) : ems_count_errors(h, j->cw, B, nberr))) die("ems_count_errors", rc);
             tallied++;
             for (int b = 0; b < B; b++) {                               /* NB_LDPC.c:474-507, frame order */
                 nb++;
@@ -223,12 +240,12 @@ int main(int argc, char *argv[])
     printf(" \n results printed \n ");
     printf("\n");
     printf("Simulation complete at time: %s", ts);
-    fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; host frame generation %.3f s on %d thread(s)\n",
-            nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, t_gen, threads);
+    fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; %s frame generation %.3f s on %d thread(s)\n",
+            nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, gpu_source ? "device-side (no host)" : "host", t_gen, gpu_source ? 0 : threads);
 
     ems_destroy(hd[0]); ems_destroy(hd[1]);
     for (int i = 0; i < NBUF; i++) { free(cwbuf[i]); free(nybuf[i]); }
-    free(col); free(coef); free(decide); free(iters); free(synd); free(nberr); free(KSYMB);
+    free(col); free(coef); free(iters); free(synd); free(nberr); free(KSYMB);
     for (int n = 0; n < N; n++) free(NBIN[n]);
     for (int k = 0; k < K; k++) free(KBIN[k]);
     free(NBIN); free(KBIN);

@@ -130,7 +130,7 @@ def _dist():
 
 
 def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=64, device=0, decode_fn=None,
-                max_err_frames=40, tensor_device="cpu", verbose=False, inflight=2):
+                max_err_frames=40, tensor_device="cpu", verbose=False, inflight=2, source="host", seed=0):
     """Run the Monte-Carlo loop over all ranks of the current process group (or one process).
 
     decode_fn(noisy, sigma, cws) -> (nberr[B], synd[B], iters[B]); default = the GPU decoder.  The CPU
@@ -139,6 +139,9 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     the results of round r are fetched, so the few frames of a round that run all iterations (its tail)
     share the GPU with the head of the next round.  Rounds are still tallied strictly in frame order; a
     round launched ahead of the 40-error stop is dropped, exactly like a frame drawn ahead of it.
+    source="host" draws the reference's own frames (drand48 stream, bit-exact traces); source="device" lets
+    the GPU generate frame f from the counter-based stream `seed` (ems_source_draw: no host work, no PCIe
+    traffic; statistical parity only) -- frame f is the same on any rank count or batch.
     Returns (Counters on every rank -- identical everywhere --, number of decode rounds)."""
     import torch
     dist = _dist()
@@ -151,14 +154,29 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
         inflight = max(1, int(inflight))
         decs = [Decoder(code, nm, NbOper, offset, NbIterMax, max_batch=batch, device=device) for _ in range(inflight)]
 
+        if source == "device":
+            for d in decs:
+                d.source_attach(src.s)
+            sigma_dev = float(np.float32(np.sqrt(1.0 / (2.0 * float(src.s.code.rate) * 10.0 ** (float(np.float32(EbN)) / 10.0)))))   # channel.c:51
+
         def submit(slot, noisy, sigma, cws):           # asynchronous: upload + ems_decode on the handle's stream
             d = decs[slot]
             B = d.llr_init(noisy, sigma)
             d.decode(B)
 
             def collect():
-                _d, iters, synd = d.results(B)
+                _d, iters, synd = d.results(B, want_decide=False)     # the error count reads the decisions in HBM
                 return d.count_errors(cws), synd, iters
+            return collect
+
+        def submit_device(slot, start, count):          # frames [start, start+count) generated and decoded in HBM
+            d = decs[slot]
+            d.source_draw(seed, start, count, sigma_dev)
+            d.decode(count)
+
+            def collect():
+                _d, iters, synd = d.results(count, want_decide=False)
+                return d.count_errors_resident(count), synd, iters
             return collect
     else:
         inflight = 1
@@ -172,9 +190,12 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     stop = False
     n_rounds = -(-NbMonteCarlo // (batch * world))
 
+    if source not in ("host", "device") or (source == "device" and not decs):
+        raise ValueError("source must be 'host' or 'device' (device needs the GPU decoder)")
+
     def draw_round(r):                                  # this rank's frames of round r (host work)
         start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
-        if count <= 0:
+        if count <= 0 or source == "device":
             return None
         src.position(start)
         return src.draw(count, EbN)
@@ -218,7 +239,9 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
         if r + 1 < n_rounds:
             pending = pool.submit(draw_round, r + 1)
         collect = None
-        if count > 0:
+        if count > 0 and source == "device":
+            collect = submit_device(r % inflight, start, count)
+        elif count > 0:
             cws, noisy, sigma = frames
             collect = submit(r % inflight, noisy, sigma, cws)
         queue.append((r, count, collect))

@@ -96,6 +96,22 @@ int ems_count_errors(ems_handle *h, const int *codewords_host, int B, int *nb_er
 int ems_set_codewords(ems_handle *h, const int *codewords_host, int B);
 int ems_count_errors_resident(ems_handle *h, int B, int *nb_errors /*[B] or NULL*/);
 
+/* ---- device-side frame source ----
+ * Replaces, for throughput runs, the host calls RandomBinaryGenerator (tools.c:124) + Encoding (tools.c:232) +
+ * the noise draw of ModelChannel_AWGN_BPSK (channel.c:52-62): information symbols, codewords and noisy BPSK
+ * samples of frames [first_frame, first_frame + B) are produced in HBM, the codewords stay resident for
+ * ems_count_errors_resident and the channel LLRs are initialised, i.e. the handle is left exactly as after
+ * ems_set_codewords + ems_llr_init.  The encoder is the reference's (bit-exact); the random stream is a
+ * counter-based Philox4x32-10 keyed by `seed` and indexed by (frame, draw) -- frame f does not depend on the
+ * batch size or on which rank draws it -- NOT libc's drand48: statistical, not bit, parity with the reference's
+ * frames (ems_draw_frames keeps the bit-exact stream on the host).
+ * ems_source_attach takes GaussianElimination's outputs: matUT as one dense row-major [M][N] block (code_t.matUT[0])
+ * and Perm [N]. */
+int ems_source_attach(ems_handle *h, const int *matUT, const int *perm);
+int ems_source_draw(ems_handle *h, unsigned long long seed, unsigned long long first_frame, int B, float sigma);
+/* copies of what ems_source_draw produced (tests): codewords [B][N] int, noisy [B][N][logGF] float; either may be NULL */
+int ems_source_get(ems_handle *h, int B, int *codewords, float *noisy);
+
 /* ---- introspection for parity tests ---- */
 int ems_get_app(ems_handle *h, int frame, float *app /*[N][GF]*/);   /* decoder_t.APP after decode      */
 int ems_get_ctov(ems_handle *h, int frame, float *ctov /*[E][GF]*/); /* decoder_t.CtoV, expanded dense */
