@@ -1700,39 +1700,60 @@ __global__ void k_v2_init(const float *__restrict__ like, const int *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Channel LLR (channel.c:66-76).  A block of 256 threads handles 256/q variable nodes, one thread per
-// (variable node, symbol).  The reference evaluates, per symbol and bit,
+// Channel LLR (channel.c:66-76).  The reference evaluates, per symbol and bit,
 //     TMP = TMP + SQR(y - BPSK(bit)) / (2.0 * SQR(sigma))        (float, float ops, double divide + add)
 // The double quotient depends only on (variable node, bit position, bit value): the 2*logq quotients of a
 // node are computed once (same operands, same IEEE divide => same bits) and every symbol then accumulates
 // them in the reference's order, rounding the running sum to float after every bit as the reference does.
 // ------------------------------------------------------------------------------------------------
+// One wavefront per variable node (q >= 64; 64/q nodes per wavefront below that), no workgroup barrier: the
+// lanes that own a (bit, value) pair publish the quotient in the wave's LDS slot, then lane i accumulates
+// symbols i*q/64 .. and stores them with one 16-byte write (q = 256).
 __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ noisy, float sigma, int logq, int q, size_t nvn,
                                                   const uint8_t *__restrict__ idx2bin, float *__restrict__ app)
 {
-    __shared__ double quo[16][8][2];                           // [node in block][bit][bit value]
-    const int per = 256 / q;                                   // variable nodes per block (q <= 256)
+    __shared__ double quo[4][4][8][2];                         // [wave][node of the wave][bit][bit value]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int vpw = q >= 64 ? 1 : 64 / q;                      // variable nodes per wavefront pass
+    const int spl = q >= 64 ? q / 64 : 1;                      // symbols per lane (<= 4)
     const double denom = 2.0 * (double)(sigma * sigma);        // 2.0*SQR(sigma), SQR in float
-    const int tid = threadIdx.x;
-    for (size_t base = (size_t)blockIdx.x * per; base < nvn; base += (size_t)gridDim.x * per) {
-        if (tid < per * logq * 2) {
-            const int v = tid / (logq * 2), r = tid - v * (logq * 2), l = r >> 1, b = r & 1;
-            if (base + v < nvn) {
-                const float s = b ? -1.0f : 1.0f;              // BPSK(x) = 1-2x (channel.h:14)
-                const float a = noisy[(base + v) * logq + l] - s;
-                const float sq = a * a;
-                quo[v][l][b] = (double)sq / denom;
+    const int nquo = vpw * logq * 2;
+    const int qv = lane / (logq * 2), qr = lane - qv * (logq * 2), ql = qr >> 1, qb = qr & 1;
+    const int v = q >= 64 ? 0 : lane / q;
+    const int g0 = q >= 64 ? lane * spl : lane - v * q;
+    unsigned img[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) img[s4] = s4 < spl ? idx2bin[g0 + s4] : 0u;
+    const size_t stride = (size_t)gridDim.x * 4 * vpw;
+    for (size_t base = ((size_t)blockIdx.x * 4 + wave) * vpw; base < nvn; base += stride) {
+        if (lane < nquo && base + qv < nvn) {
+            const float sg = qb ? -1.0f : 1.0f;                // BPSK(x) = 1-2x (channel.h:14)
+            const float a = noisy[(base + qv) * logq + ql] - sg;
+            const float sq = a * a;
+            quo[wave][qv][ql][qb] = (double)sq / denom;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (base + v < nvn) {
+            float t[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float acc = 0.0f;
+                if (s4 < spl)
+                    for (int l = 0; l < logq; ++l) acc = (float)((double)acc + quo[wave][v][l][(img[s4] >> l) & 1u]);
+                t[s4] = acc;
+            }
+            float *dst = app + (base + v) * q + g0;
+            if (spl == 4) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    if (s4 < spl) dst[s4] = t[s4];
             }
         }
-        __syncthreads();
-        const int v = tid / q, g = tid - v * q;
-        if (v < per && base + v < nvn) {
-            const unsigned img = idx2bin[g];
-            float t = 0.0f;
-            for (int l = 0; l < logq; ++l) t = (float)((double)t + quo[v][l][(img >> l) & 1u]);
-            app[(base + v) * q + g] = t;
-        }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1969,9 +1990,9 @@ hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, in
                                const uint8_t *idx2bin_dev, float *app_dev, hipStream_t st)
 {
     const size_t nvn = total / q;                              // (frame, variable node) pairs
-    const int per = 256 / q;
+    const int per = 4 * (q >= 64 ? 1 : 64 / q);                // variable nodes per block pass
     size_t blocks = (nvn + per - 1) / per;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(256), 0, st, noisy_dev, sigma, logq, q, nvn, idx2bin_dev, app_dev);
     return hipGetLastError();
 }
