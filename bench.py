@@ -154,7 +154,6 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
             out["cpu_baseline"] = cpu_baseline_v2(il.import_module("orc_v2"), matrix, nm, nop, off, itmax, sigma,
                                                    max(1, min(os.cpu_count() or 1, 16)))
         print(json.dumps(out), flush=True)
-    dec.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
@@ -294,6 +293,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tot = counters.cpu().tolist()
+    dec.close()     # frees its stream: ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, the side run below wants 3 of its own
 
     # ---- side figure (never `value`): early exit enabled at the operating point of SURVEY.md 8(d) ----
     oper = None
@@ -308,8 +308,9 @@ def main():
         Bo = 4 * B                                  # several waves of workgroups: finished frames free their CU slots for queued ones
         reps = -(-Bo // nd)
         ocw = np.tile(ocw, (reps, 1))[:Bo]; onoisy = np.tile(onoisy, (reps, 1, 1))[:Bo]
-        ods = []                                    # two handles (own streams), launched alternately as harness.monte_carlo
-        for _ in range(2):                          # does: the tail of one launch overlaps the head of the next
+        OH = 3                                      # handles (own streams) launched round-robin as harness.monte_carlo / ems_sim
+        ods = []                                    # do: the tail of one launch overlaps the head of the next ones
+        for _ in range(OH):
             od = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bo, device=local, early_exit=True)
             pkg._check(pkg.lib().ems_llr_init(od.h, pkg._ptr(onoisy), np.float32(osigma), Bo))
             od.set_codewords(ocw)
@@ -326,18 +327,22 @@ def main():
             pkg._check(pkg.lib().ems_get_results(od.h, Bo, None, pkg._ptr(it), pkg._ptr(sy)))
             return nb, it
 
-        olaunch(ods[0]); ocollect(ods[0])
-        OK = 4
+        for od in ods:
+            olaunch(od)
+        for od in ods:
+            ocollect(od)
+        OK = 3 * OH
         t1 = time.perf_counter()
-        olaunch(ods[0])
-        for k in range(1, OK):
-            olaunch(ods[k & 1])
-            onb, oit = ocollect(ods[(k - 1) & 1])
-        onb, oit = ocollect(ods[(OK - 1) & 1])
+        for k in range(OK):
+            if k >= OH:
+                onb, oit = ocollect(ods[k % OH])
+            olaunch(ods[k % OH])
+        for k in range(OK, OK + OH):
+            onb, oit = ocollect(ods[k % OH])
         odt = (time.perf_counter() - t1) / OK
         oper = {"frames_per_s": round(Bo / odt, 1), "EbN0_dB": OPER_EBN, "batch": Bo, "distinct_frames": nd,
                 "avg_iterations": round(float(oit.mean()), 2), "frame_errors": int((onb != 0).sum()),
-                "handles": 2,
+                "handles": OH,
                 "note": "early exit on (NB_LDPC.c:470); reported beside, never instead of, the fixed-work value"}
         for od in ods:
             od.close()
@@ -378,7 +383,6 @@ def main():
             threads = max(1, min(os.cpu_count() or 1, 16))
             out["cpu_baseline"] = cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads)
         print(json.dumps(out), flush=True)
-    dec.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,7 +8,7 @@
  * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH) by EMS_THREADS host
  * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
- * Two decoder handles alternate so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
+ * Several decoder handles (EMS_INFLIGHT, default 3) take turns so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
  * the frame source to the device-side counter-based generator (ems_source_draw): no host generation at all,
  * statistical instead of bit parity with the reference's frames.
  *
@@ -122,14 +122,19 @@ int main(int argc, char *argv[])
         }
     ems_code_desc desc = {code.N, code.M, code.GF, code.logGF, code.nbBranch, code.rowDegree, col, coef};
     ems_params prm = {nbMax, NbOper, offset, NbIterMax, 1};
-    /* Two decoder handles (own streams) used alternately: batch k+1 is launched before the results of batch k
-     * are fetched, so the tail of a batch (its few frames that run every iteration) overlaps the next one. */
-    ems_handle *hd[2] = {NULL, NULL};
+    /* NH decoder handles (own streams) used round-robin: up to NH batches are in flight, the results of batch k
+     * are fetched only after batch k+NH-1 has been launched, so the tail of a batch (its few frames that run every
+     * iteration) overlaps the next ones.  EMS_INFLIGHT=1..4 (default 3; 2.0 dB, GF(256): 5.5 / 6.7 / 7.4 k frames/s). */
+    enum { NH_MAX = 4 };
+    int NH = getenv("EMS_INFLIGHT") ? atoi(getenv("EMS_INFLIGHT")) : 3;
+    if (NH < 1) NH = 1;
+    if (NH > NH_MAX) NH = NH_MAX;
+    ems_handle *hd[NH_MAX] = {NULL, NULL, NULL, NULL};
     int rc;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NH; i++)
         if ((rc = ems_create(&hd[i], &desc, &prm, batch, device))) die("ems_create", rc);
     if (gpu_source)
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < NH; i++)
             if ((rc = ems_source_attach(hd[i], code.matUT[0], code.Perm))) die("ems_source_attach", rc);
     const float sigma_dev = (float)sqrt(1.0 / (2.0 * (double)code.rate * pow(10.0, (double)EbN / 10.0)));   /* channel.c:51 */
 
@@ -146,9 +151,10 @@ int main(int argc, char *argv[])
     for (int n = 0; n < N; n++) NBIN[n] = calloc(logGF, sizeof(int));
     for (int k = 0; k < K; k++) KBIN[k] = calloc(logGF, sizeof(int));
     int *KSYMB = calloc(K, sizeof(int));
-    enum { NBUF = 3 };                                                  /* being drawn / in flight / being tallied */
-    int *cwbuf[NBUF];
-    float *nybuf[NBUF];
+    enum { NBUF_MAX = NH_MAX + 1 };
+    const int NBUF = NH + 1;                                            /* NH in flight or being tallied + one being drawn */
+    int *cwbuf[NBUF_MAX];
+    float *nybuf[NBUF_MAX];
     for (int i = 0; i < NBUF; i++) {
         cwbuf[i] = malloc(sizeof(int) * (size_t)batch * N);
         nybuf[i] = malloc(sizeof(float) * (size_t)batch * N * logGF);
@@ -157,7 +163,7 @@ int main(int argc, char *argv[])
 
     int nb = 0, sum_it = 0, total_errors = 0, nbErroneousFrames = 0, nbUndetectedErrors = 0, stop = 0;
     double t_decode = 0, t_gen = 0;
-    gen_job job[NBUF];
+    gen_job job[NBUF_MAX];
     for (int i = 0; i < NBUF; i++)
         job[i] = (gen_job){&code, &table, 0, 0, threads, EbN, 0.0f, cwbuf[i], nybuf[i], NBIN, KBIN, KSYMB, &Idum, 0.0, 0};
     pthread_t producer;
@@ -168,7 +174,7 @@ int main(int argc, char *argv[])
     if (!gpu_source) generate(&job[0]);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    int launched = 0, tallied = 0;                                      /* batch counters; batch k uses job[k % NBUF], hd[k & 1] */
+    int launched = 0, tallied = 0;                                      /* batch counters; batch k uses job[k % NBUF], hd[k % NH] */
     for (;;) {
         int have_next = 0, more = 0;
         if ((long)launched * batch < NbMonteCarlo) {
@@ -187,7 +193,7 @@ int main(int argc, char *argv[])
                 have_next = pthread_create(&producer, NULL, generate, n) == 0;
                 if (!have_next) generate(n);
             }
-            ems_handle *h = hd[launched & 1];                           /* asynchronous: upload, LLR kernel, decode kernel */
+            ems_handle *h = hd[launched % NH];                          /* asynchronous: upload, LLR kernel, decode kernel */
             if (gpu_source) {
                 if ((rc = ems_source_draw(h, gpu_seed, (unsigned long long)j->first, j->B, sigma_dev))) die("ems_source_draw", rc);
             } else if ((rc = ems_llr_init(h, j->noisy, j->sigma, j->B))) die("ems_llr_init", rc);
@@ -195,9 +201,9 @@ int main(int argc, char *argv[])
             launched++;
             more = 1;
         }
-        if (launched - tallied == 2 || (!more && launched > tallied)) { /* fetch the older batch (blocks on its stream) */
+        if (launched - tallied == NH || (!more && launched > tallied)) { /* fetch the older batch (blocks on its stream) */
             gen_job *j = &job[tallied % NBUF];
-            ems_handle *h = hd[tallied & 1];
+            ems_handle *h = hd[tallied % NH];
             const int B = j->B;
             if ((rc = ems_get_results(h, B, NULL, iters, synd))) die("ems_get_results", rc);   /* decisions stay in HBM */
             if ((rc = gpu_source ? ems_count_errors_resident(h, B, nberr) : ems_count_errors(h, j->cw, B, nberr))) die("ems_count_errors", rc);
@@ -220,7 +226,7 @@ int main(int argc, char *argv[])
         if (have_next) pthread_join(producer, NULL);                    /* (dropped if the 40-error stop came first) */
         if (stop || (!more && launched == tallied)) break;
     }
-    for (int i = 0; i < 2; i++) ems_synchronize(hd[i]);                 /* a batch launched ahead of the stop is dropped */
+    for (int i = 0; i < NH; i++) ems_synchronize(hd[i]);                 /* a batch launched ahead of the stop is dropped */
     clock_gettime(CLOCK_MONOTONIC, &t1);
     t_decode = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
@@ -243,7 +249,7 @@ int main(int argc, char *argv[])
     fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; %s frame generation %.3f s on %d thread(s)\n",
             nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, gpu_source ? "device-side (no host)" : "host", t_gen, gpu_source ? 0 : threads);
 
-    ems_destroy(hd[0]); ems_destroy(hd[1]);
+    for (int i = 0; i < NH; i++) ems_destroy(hd[i]);
     for (int i = 0; i < NBUF; i++) { free(cwbuf[i]); free(nybuf[i]); }
     free(col); free(coef); free(iters); free(synd); free(nberr); free(KSYMB);
     for (int n = 0; n < N; n++) free(NBIN[n]);

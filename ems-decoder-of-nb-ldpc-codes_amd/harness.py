@@ -130,7 +130,7 @@ def _dist():
 
 
 def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=64, device=0, decode_fn=None,
-                max_err_frames=40, tensor_device="cpu", verbose=False, inflight=2, source="host", seed=0):
+                max_err_frames=40, tensor_device="cpu", verbose=False, inflight=3, source="host", seed=0):
     """Run the Monte-Carlo loop over all ranks of the current process group (or one process).
 
     decode_fn(noisy, sigma, cws) -> (nberr[B], synd[B], iters[B]); default = the GPU decoder.  The CPU

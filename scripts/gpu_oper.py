@@ -51,16 +51,22 @@ for Bo in [int(x) for x in os.environ.get("OPER_B", "1024,2048,4096,8192").split
         launch(od, Bo); nb, it = collect(od, Bo)
     dt = (time.perf_counter() - t) / 3
     print("one handle  B=%5d: %7.1f frames/s  avg it %.2f  FE %d" % (Bo, Bo / dt, it.mean(), (nb != 0).sum()), flush=True)
-    od2 = mk(Bo)
-    hs = [od, od2]
-    launch(hs[0], Bo); launch(hs[1], Bo); collect(hs[0], Bo); collect(hs[1], Bo)
-    K = 6
-    t = time.perf_counter()
-    launch(hs[0], Bo)
-    for k in range(1, K):
-        launch(hs[k & 1], Bo)
-        collect(hs[(k - 1) & 1], Bo)
-    collect(hs[(K - 1) & 1], Bo)
-    dt = (time.perf_counter() - t) / K
-    print("two handles B=%5d: %7.1f frames/s" % (Bo, Bo / dt), flush=True)
-    od.close(); od2.close()
+    for H in (2, 3):
+        hs = [od] + [mk(Bo) for _ in range(H - 1)]
+        for h in hs:
+            launch(h, Bo)
+        for h in hs:
+            collect(h, Bo)
+        K = 9
+        t = time.perf_counter()
+        for k in range(K):
+            if k >= H:
+                collect(hs[k % H], Bo)
+            launch(hs[k % H], Bo)
+        for k in range(K, K + H):
+            collect(hs[k % H], Bo)
+        dt = (time.perf_counter() - t) / K
+        print("%d handles   B=%5d: %7.1f frames/s" % (H, Bo, Bo / dt), flush=True)
+        for h in hs[1:]:
+            h.close()
+    od.close()
