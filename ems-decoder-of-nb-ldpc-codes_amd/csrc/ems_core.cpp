@@ -530,7 +530,7 @@ int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B)
     if (r) return r;
     if (!noisy_dev) return fail(EMS_EINVAL, "null noisy pointer");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    HIP_TRY(ems_launch_llr_init(noisy_dev, sigma, h->logq, h->q, (size_t)B * h->N * h->q, h->d_i2b.p, h->d_app.p, h->stream));
+    HIP_TRY(ems_launch_llr_init(noisy_dev, sigma, h->logq, h->q, (size_t)B * h->N * h->q, h->d_i2b.p, h->d_b2i.p, h->d_app.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
     return EMS_OK;

@@ -1707,25 +1707,26 @@ __global__ void k_v2_init(const float *__restrict__ like, const int *__restrict_
 // them in the reference's order, rounding the running sum to float after every bit as the reference does.
 // ------------------------------------------------------------------------------------------------
 // One wavefront per variable node (q >= 64; 64/q nodes per wavefront below that), no workgroup barrier: the
-// lanes that own a (bit, value) pair publish the quotient in the wave's LDS slot, then lane i accumulates
-// symbols i*q/64 .. and stores them with one 16-byte write (q = 256).
+// lanes that own a (bit, value) pair publish the quotient in the wave's LDS slot.  The running sum of a symbol
+// after bit l depends only on the low l+1 bits of its binary image, so for q >= 64 lane i runs the chain once
+// for the six low bits (= i) and then extends it over the high bits for the q/64 images i + 64h -- 12 rounded
+// additions instead of 32 for q = 256, each one the very operation the reference performs for that symbol.
+// The results go through a per-wave LDS row (image -> symbol index) and leave as one 16-byte store per lane.
 __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ noisy, float sigma, int logq, int q, size_t nvn,
-                                                  const uint8_t *__restrict__ idx2bin, float *__restrict__ app)
+                                                  const uint8_t *__restrict__ idx2bin, const uint8_t *__restrict__ bin2idx,
+                                                  float *__restrict__ app)
 {
     __shared__ double quo[4][4][8][2];                         // [wave][node of the wave][bit][bit value]
+    __shared__ __attribute__((aligned(16))) float row[4][256]; // [wave][symbol]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int vpw = q >= 64 ? 1 : 64 / q;                      // variable nodes per wavefront pass
     const int spl = q >= 64 ? q / 64 : 1;                      // symbols per lane (<= 4)
     const double denom = 2.0 * (double)(sigma * sigma);        // 2.0*SQR(sigma), SQR in float
     const int nquo = vpw * logq * 2;
     const int qv = lane / (logq * 2), qr = lane - qv * (logq * 2), ql = qr >> 1, qb = qr & 1;
-    const int v = q >= 64 ? 0 : lane / q;
-    const int g0 = q >= 64 ? lane * spl : lane - v * q;
-    unsigned img[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) img[s4] = s4 < spl ? idx2bin[g0 + s4] : 0u;
     const size_t stride = (size_t)gridDim.x * 4 * vpw;
-    for (size_t base = ((size_t)blockIdx.x * 4 + wave) * vpw; base < nvn; base += stride) {
+    const size_t first = ((size_t)blockIdx.x * 4 + wave) * vpw;
+    auto publish = [&](size_t base) {
         if (lane < nquo && base + qv < nvn) {
             const float sg = qb ? -1.0f : 1.0f;                // BPSK(x) = 1-2x (channel.h:14)
             const float a = noisy[(base + qv) * logq + ql] - sg;
@@ -1734,26 +1735,53 @@ __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ nois
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (base + v < nvn) {
-            float t[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                float acc = 0.0f;
-                if (s4 < spl)
-                    for (int l = 0; l < logq; ++l) acc = (float)((double)acc + quo[wave][v][l][(img[s4] >> l) & 1u]);
-                t[s4] = acc;
-            }
-            float *dst = app + (base + v) * q + g0;
-            if (spl == 4) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(t[0], t[1], t[2], t[3]);
-            } else {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    if (s4 < spl) dst[s4] = t[s4];
-            }
-        }
+    };
+    auto retire = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+    if (q >= 64) {
+        int g[4];                                              // symbol index of image lane + 64h
+#pragma unroll
+        for (int h = 0; h < 4; ++h) g[h] = h < spl ? bin2idx[lane + 64 * h] : 0;
+        for (size_t base = first; base < nvn; base += stride) {
+            publish(base);
+            float t = 0.0f;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) t = (float)((double)t + quo[wave][0][l][(lane >> l) & 1]);
+            if (spl == 1) {
+                row[wave][g[0]] = t;
+            } else if (spl == 2) {
+                row[wave][g[0]] = (float)((double)t + quo[wave][0][6][0]);
+                row[wave][g[1]] = (float)((double)t + quo[wave][0][6][1]);
+            } else {
+                const float t0 = (float)((double)t + quo[wave][0][6][0]), t1 = (float)((double)t + quo[wave][0][6][1]);
+                const double q70 = quo[wave][0][7][0], q71 = quo[wave][0][7][1];
+                row[wave][g[0]] = (float)((double)t0 + q70);   // image bits (7,6) = 00, 01, 10, 11
+                row[wave][g[1]] = (float)((double)t1 + q70);
+                row[wave][g[2]] = (float)((double)t0 + q71);
+                row[wave][g[3]] = (float)((double)t1 + q71);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float *dst = app + base * q;
+            if (spl == 4) *reinterpret_cast<float4 *>(dst + 4 * lane) = *reinterpret_cast<const float4 *>(&row[wave][4 * lane]);
+            else if (spl == 2) *reinterpret_cast<float2 *>(dst + 2 * lane) = *reinterpret_cast<const float2 *>(&row[wave][2 * lane]);
+            else dst[lane] = row[wave][lane];
+            retire();
+        }
+        return;
+    }
+    const int v = lane / q, g0 = lane - v * q;
+    const unsigned img = idx2bin[g0];
+    for (size_t base = first; base < nvn; base += stride) {
+        publish(base);
+        if (base + v < nvn) {
+            float acc = 0.0f;
+            for (int l = 0; l < logq; ++l) acc = (float)((double)acc + quo[wave][v][l][(img >> l) & 1u]);
+            app[(base + v) * q + g0] = acc;
+        }
+        retire();
     }
 }
 
@@ -1987,13 +2015,13 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
 }
 
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
-                               const uint8_t *idx2bin_dev, float *app_dev, hipStream_t st)
+                               const uint8_t *idx2bin_dev, const uint8_t *bin2idx_dev, float *app_dev, hipStream_t st)
 {
     const size_t nvn = total / q;                              // (frame, variable node) pairs
     const int per = 4 * (q >= 64 ? 1 : 64 / q);                // variable nodes per block pass
     size_t blocks = (nvn + per - 1) / per;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(256), 0, st, noisy_dev, sigma, logq, q, nvn, idx2bin_dev, app_dev);
+    hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(256), 0, st, noisy_dev, sigma, logq, q, nvn, idx2bin_dev, bin2idx_dev, app_dev);
     return hipGetLastError();
 }
 
