@@ -77,6 +77,9 @@ int main(int argc, char *argv[])
                "\n\t NbOper           : Maximum number of operations for sorting \n");
         return EXIT_FAILURE;
     }
+    /* one HIP stream per decoder handle: keep them on distinct hardware queues (ROCm's default is 4 queues for all
+     * streams of the process; streams that share one serialise).  Must be set before the first HIP call. */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const int NbMonteCarlo = atoi(argv[1]);
     const int NbIterMax = atoi(argv[2]);
     char *FileMatrix = argv[3];

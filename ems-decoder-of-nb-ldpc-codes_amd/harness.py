@@ -20,6 +20,11 @@ import os
 import numpy as np
 
 from . import Code, Decoder
+# monte_carlo keeps `inflight` decoder handles busy, one HIP stream each, next to torch's and RCCL's streams; ROCm
+# multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues and streams that share
+# one serialise.  Only effective when this module is imported before the process's first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .refapi import RefSession, seed48
 
 LCG_A = 0x5DEECE66D
