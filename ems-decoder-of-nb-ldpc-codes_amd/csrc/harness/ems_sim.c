@@ -35,12 +35,14 @@ static void die(const char *what, int rc)
  * previous one. */
 typedef struct {
     code_t *code; table_t *table;
-    int first, B, threads;                  /* frames [first, first+B) of the stream */
+    long first;                             /* frames [first, first+B) of the stream */
+    int B, threads;
     float EbN, sigma;
     int *cw; float *noisy;                  /* [B][N], [B][N][logGF] */
     int **NBIN, **KBIN, *KSYMB, *Idum;      /* scratch of the serial (threads == 1) path */
     double seconds;
     int rc;
+    int offset_run;                         /* EMS_FIRST_FRAME != 0: libc's drand48 cannot be positioned, use the library's generator */
 } gen_job;
 
 static void *generate(void *arg)
@@ -49,7 +51,7 @@ static void *generate(void *arg)
     struct timespec g0, g1;
     clock_gettime(CLOCK_MONOTONIC, &g0);
     j->rc = 0;
-    if (j->threads > 1) {                   /* same bits, frame-parallel (nbldpc_ref_api.h) */
+    if (j->threads > 1 || j->offset_run) {  /* same bits, frame-parallel, any starting frame (nbldpc_ref_api.h) */
         j->rc = ems_draw_frames(j->code, j->table, j->first, j->B, j->EbN, j->threads, j->cw, j->noisy, &j->sigma);
     } else {
         const int N = j->code->N, logGF = j->code->logGF;
@@ -98,6 +100,9 @@ int main(int argc, char *argv[])
      * parity with the reference's trace. */
     const int gpu_source = getenv("EMS_GPU_SOURCE") != NULL;
     const unsigned long long gpu_seed = gpu_source ? strtoull(getenv("EMS_GPU_SOURCE"), NULL, 0) : 0ULL;
+    /* EMS_FIRST_FRAME=<f>: this process simulates frames [f, f + NbMonteCarlo) of the stream (0-based), e.g. one process
+     * per GPU on disjoint ranges; 0 = the reference's run. */
+    const long first_frame = getenv("EMS_FIRST_FRAME") ? atol(getenv("EMS_FIRST_FRAME")) : 0L;
     int Idum = -1;
 
     printf(" Monte-Carlo simulation of Non-Binary LDPC decoder \n\n");
@@ -168,10 +173,10 @@ int main(int argc, char *argv[])
     double t_decode = 0, t_gen = 0;
     gen_job job[NBUF_MAX];
     for (int i = 0; i < NBUF; i++)
-        job[i] = (gen_job){&code, &table, 0, 0, threads, EbN, 0.0f, cwbuf[i], nybuf[i], NBIN, KBIN, KSYMB, &Idum, 0.0, 0};
+        job[i] = (gen_job){&code, &table, 0, 0, threads, EbN, 0.0f, cwbuf[i], nybuf[i], NBIN, KBIN, KSYMB, &Idum, 0.0, 0, first_frame != 0};
     pthread_t producer;
     int drawn = 0;                                                      /* frames handed to the generator so far */
-    job[0].first = 0;
+    job[0].first = first_frame;
     job[0].B = NbMonteCarlo < batch ? NbMonteCarlo : batch;
     drawn = job[0].B;
     if (!gpu_source) generate(&job[0]);
@@ -183,14 +188,14 @@ int main(int argc, char *argv[])
         if ((long)launched * batch < NbMonteCarlo) {
             gen_job *j = &job[launched % NBUF];
             if (gpu_source) {
-                j->first = launched * batch;
-                j->B = (NbMonteCarlo - j->first) < batch ? (int)(NbMonteCarlo - j->first) : batch;
+                j->first = first_frame + (long)launched * batch;
+                j->B = (NbMonteCarlo - launched * batch) < batch ? NbMonteCarlo - launched * batch : batch;
             }
             if (j->rc) die("ems_draw_frames", j->rc);
             t_gen += j->seconds;
             if (!gpu_source && drawn < NbMonteCarlo) {                  /* draw the next batch while this one decodes */
                 gen_job *n = &job[(launched + 1) % NBUF];
-                n->first = drawn;
+                n->first = first_frame + drawn;
                 n->B = (NbMonteCarlo - drawn) < batch ? (NbMonteCarlo - drawn) : batch;
                 drawn += n->B;
                 have_next = pthread_create(&producer, NULL, generate, n) == 0;

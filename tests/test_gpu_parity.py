@@ -417,3 +417,25 @@ def test_python_driver_single_rank_gpu(harness, kat):
     cnt, _ = harness.monte_carlo(os.path.join(MAT, "KN_N96_K48_GF64.txt"), k["frames"], k["NbIterMax"], k["EbN"], k["nm"], k["offset"],
                                  k["NbOper"], batch=32)
     assert [list(t) for t in cnt.trace] == [list(t) for t in k["trace"]]
+
+
+def test_c_harness_first_frame_offset(pkg, kat, tmp_path):
+    """EMS_FIRST_FRAME=f: the process simulates frames f.. of the reference's stream (one process per GPU on disjoint
+    ranges); frames 3..11 of K1 give K1's trace minus its first three frames, with either generator."""
+    k = kat["K1"]
+    full = [list(t) for t in k["trace"]]                     # cumulative (errFrames, bitErr, "avr_it")
+    sum_it = [round(float(t[2]) * (i + 1)) for i, t in enumerate(full)]
+    want = []
+    for i in range(3, len(full)):
+        n = i - 2
+        want.append([full[i][0] - full[2][0], full[i][1] - full[2][1], "%.2f" % ((sum_it[i] - sum_it[2]) / n)])
+    for threads in ("1", "4"):
+        os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
+        out = subprocess.run([pkg.SIM_PATH, str(len(full) - 3), str(k["NbIterMax"]), os.path.join(MAT, "KN_N96_K48_GF64.txt"), str(k["EbN"]),
+                              str(k["nm"]), str(k["offset"]), str(k["NbOper"])], cwd=str(tmp_path),
+                             env=dict(os.environ, EMS_BATCH="4", EMS_FIRST_FRAME="3", EMS_THREADS=threads), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        tr = [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
+              re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", out.stdout.decode("latin-1"))]
+        assert tr == want
