@@ -588,14 +588,13 @@ int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd)
 {
     int r = check_batch(h, B);
     if (r) return r;
+    // copies ride the handle's own stream (other handles' launches keep running; nothing touches the null stream)
+    std::vector<uint8_t> tmp(decide ? (size_t)B * h->N : 0);
+    if (decide) HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_decide.p, tmp.size(), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (synd) HIP_TRY(hipMemcpyAsync(synd, h->d_synd.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (decide) {
-        std::vector<uint8_t> tmp((size_t)B * h->N);
-        HIP_TRY(hipMemcpy(tmp.data(), h->d_decide.p, tmp.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < tmp.size(); ++i) decide[i] = tmp[i];
-    }
-    if (iters) HIP_TRY(hipMemcpy(iters, h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
-    if (synd) HIP_TRY(hipMemcpy(synd, h->d_synd.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) decide[i] = tmp[i];
     return EMS_OK;
 }
 

@@ -7,7 +7,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 W = {"gf256": ("Ahmed_64800_R12_GF256", 20, 40, 30, 1.0, 256), "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 30, 0.0, 256),
      "n96": ("N96_K48_GF64", 16, 32, 30, -3.0, 8192)}
-names = ["load+Mvc", "select", "ES stages", "expand+store+decide", "level barrier wait", "syndrome", "wave idle (no CN)", "-"]
+names = ["load+Mvc", "select", "ES stages", "expand+store+decide", "level barrier wait", "syndrome", "wave idle (no CN)", "sweep-end barrier"]
 for w in (sys.argv[1:] or ["gf256"]):
     B = None
     if ":" in w: w, B = w.split(":"); B = int(B)
@@ -26,11 +26,11 @@ for w in (sys.argv[1:] or ["gf256"]):
     print("%s B=%d decode %.2f ms (stamped build)" % (w, B, ms))
     for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
         tot = float(st[grp:grp + 8].sum()) or 1.0
-        print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(7)))
+        print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(8)))
     w0 = st[0:8].astype(np.float64); nw = int(os.environ.get("EMS_WAVES", "9")) * B if os.environ.get("EMS_WAVES") else 9 * B
     per_wave_cycles = w0.sum() / nw
     visits = code.M * (itmax - 1) * B
-    print("  cycles per visit by phase: " + ", ".join("%s %.0f" % (names[i], float(st[i] + st[8 + i]) / visits) for i in range(7)))
+    print("  cycles per visit by phase: " + ", ".join("%s %.0f" % (names[i], float(st[i] + st[8 + i]) / visits) for i in range(8)))
     print("  cycles per wave (waves 0-8 avg): %.3e ; => clock ~ %.2f GHz if the kernel took %.1f ms" % (per_wave_cycles, per_wave_cycles / (ms * 1e-3) / 1e9, ms))
     d = st[16:24].astype(np.float64)
     print("  selections(wave) %d, threshold iterations/selection %.2f, slow-path fraction %.4f; ES stages %d, continuation fraction %.4f, tie-fallback fraction %.4f, long-continuation fraction %.4f" % (d[0], d[1] / max(d[0], 1), d[2] / max(d[0], 1), d[3], d[4] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1)))

@@ -1,0 +1,29 @@
+"""Generates tests/golden/kat_long.json: the trace the REAL reference executable (oracle/_ref/essai_ubs, built from
+/root/reference by oracle/Makefile) prints for a complete operating-point run of the headline code -- every frame
+up to the 40th erroneous one (NB_LDPC.c:506) at 2.0 dB -- so that the GPU harness can be held to the reference
+over several hundred full-size frames, not a handful.  Takes the reference about half an hour on one core.
+
+    python tests/golden/make_kat_long.py            (needs /root/reference; run from the repo root)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+
+CASES = {
+    "L4": dict(matrix="Ahmed_64800_R12_GF256", fmt="ubs", frames=2000, NbIterMax=30, EbN=2.0, nm=20, offset=0.3, NbOper=40),
+}
+
+if __name__ == "__main__":
+    orc.build()
+    out = {}
+    for name, c in CASES.items():
+        path = os.path.join(ROOT, "tests", "golden", "matrices", c["matrix"])
+        tr = orc.run_reference_binary(c["fmt"], c["frames"], c["NbIterMax"], path, c["EbN"], c["nm"], c["offset"], c["NbOper"],
+                                      timeout=6 * 3600)
+        out[name] = dict(c, trace=[list(t) for t in tr])
+        print(name, len(tr), "frames, last", tr[-1], flush=True)
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "kat_long.json"), "w"))

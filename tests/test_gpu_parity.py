@@ -3,6 +3,7 @@ the golden vectors generated from the reference and against the CPU oracle on th
 Bar: bit-exact for everything on the decode path (hard decisions, syndrome, iteration counts, APP and
 CtoV floats -- the path uses only f32 add/sub/compare, so the tolerance is 0 ulp); the channel LLR is
 also required bit-exact (tolerance 0: the kernel keeps the reference's float/double promotion order)."""
+import json
 import os
 import re
 import subprocess
@@ -10,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import MAT, FieldOracle, es_case_fields, gold
+from conftest import GOLD, MAT, FieldOracle, es_case_fields, gold
 
 pytestmark = pytest.mark.gpu
 
@@ -439,3 +440,17 @@ def test_c_harness_first_frame_offset(pkg, kat, tmp_path):
         tr = [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
               re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", out.stdout.decode("latin-1"))]
         assert tr == want
+
+
+def test_c_harness_full_operating_point_run(pkg, tmp_path):
+    """A complete Monte-Carlo point of the headline code (2.0 dB, up to the 40th erroneous frame, several hundred
+    full-size frames): the GPU harness prints the trace the real reference executable printed
+    (tests/golden/kat_long.json, generated by tests/golden/make_kat_long.py)."""
+    path = os.path.join(GOLD, "kat_long.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/kat_long.json not generated")
+    k = json.load(open(path))["L4"]
+    tr = _run_ems_sim(pkg, [k["frames"], k["NbIterMax"], os.path.join(MAT, k["matrix"]), k["EbN"], k["nm"], k["offset"], k["NbOper"]],
+                      512, str(tmp_path))
+    assert len(tr) == len(k["trace"]) and tr[-1][0] == 40
+    assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
