@@ -634,12 +634,13 @@ int ems_source_attach(ems_handle *h, const int *matUT, const int *perm)
 {
     if (!h || !matUT || !perm) return fail(EMS_EINVAL, "null argument");
     const int N = h->N, M = h->M;
-    std::vector<int> tptr(M + 1, 0), rptr(M + 1, 0), tcol, rcol, pv(perm, perm + N);
+    std::vector<int> tptr(M + 1, 0), rptr(M + 1, 0), tcol, rcol, pv(N, 0);     // pv: inverse permutation
     std::vector<uint8_t> tcoef, rcoef, diag(M);
     std::vector<char> seen(N, 0);
     for (int n = 0; n < N; ++n) {
         if (perm[n] < 0 || perm[n] >= N || seen[perm[n]]) return fail(EMS_EINVAL, "Perm is not a permutation of 0..N-1");
         seen[perm[n]] = 1;
+        pv[perm[n]] = n;
     }
     for (int m = 0; m < M; ++m) {
         const int *row = matUT + (size_t)m * N;
@@ -673,7 +674,7 @@ int ems_source_attach(ems_handle *h, const int *matUT, const int *perm)
     S.N = N; S.M = M; S.K = h->K; S.q = h->q; S.logq = h->logq; S.Bs = h->max_batch;
     S.tptr = h->d_src_tptr.p; S.tcol = h->d_src_tcol.p; S.tcoef = h->d_src_tcoef.p;
     S.rptr = h->d_src_rptr.p; S.rcol = h->d_src_rcol.p; S.rcoef = h->d_src_rcoef.p;
-    S.diag = h->d_src_diag.p; S.perm = h->d_src_perm.p; S.idx2bin = h->d_i2b.p; S.bin2idx = h->d_b2i.p;
+    S.diag = h->d_src_diag.p; S.iperm = h->d_src_perm.p; S.idx2bin = h->d_i2b.p; S.bin2idx = h->d_b2i.p;
     S.sym = h->d_src_sym.p; S.rhs = h->d_src_rhs.p;
     h->src_ready = true;
     return EMS_OK;

@@ -87,7 +87,7 @@ struct EmsSourcePlan {
     const int *rptr, *rcol; // information part: entries with col >= M
     const uint8_t *rcoef;
     const uint8_t *diag;    // [M] matUT[m][m]
-    const int *perm;        // [N] code_t.Perm
+    const int *iperm;       // [N] inverse of code_t.Perm: codeword position -> matUT column
     const uint8_t *idx2bin, *bin2idx;
     uint8_t *sym;           // [N][Bs] symbols in matUT column order
     uint8_t *rhs;           // [M][Bs] binary image of the information part's contribution to row m

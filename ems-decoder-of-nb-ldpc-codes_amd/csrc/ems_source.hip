@@ -113,8 +113,8 @@ __global__ void k_src_solve(int B, int Bs, int M, int qm1, const int *__restrict
     }
 }
 
-// CodeWord[Perm[n]] = sym[n] (tools.c:252), then noisy = (1 - 2 bit) + sigma * gauss per bit of the binary
-// image (channel.c:52-62 with the device stream).  Stream 1, block j of frame f gives samples 2j and 2j+1
+// CodeWord[Perm[n]] = sym[n] (tools.c:252; walked by codeword position through the inverse permutation), then
+// noisy = (1 - 2 bit) + sigma * gauss per bit of the binary image (channel.c:52-62 with the device stream).  Stream 1, block j of frame f gives samples 2j and 2j+1
 // (sample index = codeword position * logq + bit); u in (0,1], v in [0,1) on a 2^-24 grid; Box-Muller in f32.
 __device__ __forceinline__ float box_muller(uint32_t wu, uint32_t wv)
 {
@@ -124,13 +124,13 @@ __device__ __forceinline__ float box_muller(uint32_t wu, uint32_t wv)
 }
 
 __global__ void k_src_channel(uint64_t seed, uint64_t first_frame, int B, int Bs, int N, int logq, float sigma,
-                              const int *__restrict__ perm, const uint8_t *__restrict__ idx2bin,
+                              const int *__restrict__ iperm, const uint8_t *__restrict__ idx2bin,
                               const uint8_t *__restrict__ sym, int *__restrict__ cw, float *__restrict__ noisy)
 {
     const size_t total = (size_t)B * N;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int f = (int)(t / N), n = (int)(t % N);
-        const int pos = perm[n];
+        const int f = (int)(t / N), pos = (int)(t % N);       // consecutive lanes = consecutive codeword positions: coalesced stores
+        const int n = iperm[pos];
         const int s = sym[(size_t)n * Bs + f];
         cw[(size_t)f * N + pos] = s;
         const unsigned img = idx2bin[s];
@@ -170,7 +170,7 @@ hipError_t ems_launch_source(const EmsSourcePlan &S, uint64_t seed, uint64_t fir
     {
         const size_t total = (size_t)B * S.N;
         const unsigned blocks = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
-        hipLaunchKernelGGL(k_src_channel, dim3(blocks), dim3(256), 0, st, seed, first_frame, B, S.Bs, S.N, S.logq, sigma, S.perm, S.idx2bin,
+        hipLaunchKernelGGL(k_src_channel, dim3(blocks), dim3(256), 0, st, seed, first_frame, B, S.Bs, S.N, S.logq, sigma, S.iperm, S.idx2bin,
                            S.sym, cw_dev, noisy_dev);
     }
     return hipGetLastError();

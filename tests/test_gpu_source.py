@@ -165,3 +165,27 @@ def test_c_harness_with_device_source(pkg, tmp_path):
     ef, nb = int(outs[0][-1][0]), int(outs[0][-1][1])
     assert ef == 40 or nb == 2000
     assert 0.004 < ef / nb < 0.04
+
+
+def test_source_error_paths(pkg, refapi):
+    path = os.path.join(MAT, "N96_K48_GF64")
+    s = refapi.RefSession(path, 16, need_encoder=True)
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 5, max_batch=8)
+    with pytest.raises(pkg.EmsError) as e:                  # not attached yet
+        dec.source_draw(1, 0, 4, 0.5)
+    assert e.value.code == pkg.EMS_EINVAL
+    N, M = s.N, s.M
+    matUT = np.ctypeslib.as_array(s.code.matUT[0], shape=(M * N,)).reshape(M, N).copy()
+    perm = np.ctypeslib.as_array(s.code.Perm, shape=(N,)).copy()
+    L = pkg.lib()
+    bad = perm.copy(); bad[0] = bad[1]                      # not a permutation
+    assert L.ems_source_attach(dec.h, pkg._ptr(matUT), pkg._ptr(bad)) == pkg.EMS_EINVAL
+    low = matUT.copy(); low[3, 1] = 5                       # below the diagonal
+    assert L.ems_source_attach(dec.h, pkg._ptr(low), pkg._ptr(perm)) == pkg.EMS_EINVAL
+    zp = matUT.copy(); zp[2, 2] = 0                         # zero pivot
+    assert L.ems_source_attach(dec.h, pkg._ptr(zp), pkg._ptr(perm)) == pkg.EMS_EINVAL
+    assert L.ems_source_attach(dec.h, pkg._ptr(matUT), pkg._ptr(perm)) == 0
+    with pytest.raises(pkg.EmsError):                       # batch above the handle's capacity
+        dec.source_draw(1, 0, 9, 0.5)
+    dec.source_draw(1, 0, 8, 0.5)
+    dec.close(); s.close()
