@@ -15,15 +15,20 @@ import orc  # noqa: E402
 
 CASES = {
     "L4": dict(matrix="Ahmed_64800_R12_GF256", fmt="ubs", frames=2000, NbIterMax=30, EbN=2.0, nm=20, offset=0.3, NbOper=40),
+    "L3a": dict(matrix="Ahmed_64800_R34_GF16", fmt="ubs", frames=400, NbIterMax=30, EbN=3.0, nm=8, offset=0.3, NbOper=16),
+    "L3b": dict(matrix="Ahmed_64800_R34_GF16", fmt="ubs", frames=150, NbIterMax=30, EbN=2.3, nm=8, offset=0.3, NbOper=16),
 }
 
 if __name__ == "__main__":
     orc.build()
-    out = {}
+    dst = os.path.join(ROOT, "tests", "golden", "kat_long.json")
+    out = json.load(open(dst)) if os.path.exists(dst) else {}
     for name, c in CASES.items():
+        if name in out and {k: out[name][k] for k in c} == c:
+            continue                                    # already generated with these parameters
         path = os.path.join(ROOT, "tests", "golden", "matrices", c["matrix"])
         tr = orc.run_reference_binary(c["fmt"], c["frames"], c["NbIterMax"], path, c["EbN"], c["nm"], c["offset"], c["NbOper"],
                                       timeout=6 * 3600)
         out[name] = dict(c, trace=[list(t) for t in tr])
         print(name, len(tr), "frames, last", tr[-1], flush=True)
-    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "kat_long.json"), "w"))
+        json.dump(out, open(dst, "w"))

@@ -442,15 +442,16 @@ def test_c_harness_first_frame_offset(pkg, kat, tmp_path):
         assert tr == want
 
 
-def test_c_harness_full_operating_point_run(pkg, tmp_path):
-    """A complete Monte-Carlo point of the headline code (2.0 dB, up to the 40th erroneous frame, several hundred
-    full-size frames): the GPU harness prints the trace the real reference executable printed
-    (tests/golden/kat_long.json, generated by tests/golden/make_kat_long.py)."""
+@pytest.mark.parametrize("case,batch", [("L4", 512), ("L3a", 128), ("L3b", 64)])
+def test_c_harness_full_operating_point_run(pkg, tmp_path, case, batch):
+    """Complete Monte-Carlo points of the 64800-bit codes (several hundred full-size frames each; L4 runs to the 40th
+    erroneous frame of the headline code at 2.0 dB): the GPU harness prints the trace the real reference executable
+    printed (tests/golden/kat_long.json, generated by tests/golden/make_kat_long.py)."""
     path = os.path.join(GOLD, "kat_long.json")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/kat_long.json not generated")
-    k = json.load(open(path))["L4"]
+    if not os.path.exists(path) or case not in json.load(open(path)):
+        pytest.skip("tests/golden/kat_long.json has no case " + case)
+    k = json.load(open(path))[case]
     tr = _run_ems_sim(pkg, [k["frames"], k["NbIterMax"], os.path.join(MAT, k["matrix"]), k["EbN"], k["nm"], k["offset"], k["NbOper"]],
-                      512, str(tmp_path))
-    assert len(tr) == len(k["trace"]) and tr[-1][0] == 40
+                      batch, str(tmp_path))
+    assert len(tr) == len(k["trace"]) and (tr[-1][0] == 40 or len(tr) == k["frames"])
     assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
