@@ -157,3 +157,30 @@ def test_v2_rejects_what_it_does_not_build(pkg, v2):
     with pytest.raises(pkg.EmsError):
         dec.v2_load_likelihood(like[None], idx[None])
     dec.close()
+
+
+def test_v2_long_golden_run_from_the_reference(pkg, orc, v2):
+    """48 full-size frames (easy to non-converging) decoded by the real v2 functions (tests/golden/v2_frames_long.npz,
+    make_golden_v2_long.py): iterations, syndrome, hard decisions and every state array (CRC-32) of one batched GPU
+    decode."""
+    p = os.path.join(ROOT, "tests", "golden", "v2_frames_long.npz")
+    if not os.path.exists(p):
+        pytest.skip("tests/golden/v2_frames_long.npz not generated")
+    g = np.load(p)
+    nm, nop, off, itmax = int(g["params"][0]), int(g["params"][1]), float(g["params"][2]), int(g["params"][3])
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = v2.V2Oracle(path)
+    cases = g["cases"]
+    B = len(cases)
+    dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=B)
+    like = np.zeros((B, o.N, 256), np.float32)
+    idx = np.zeros((B, o.N, 256), np.int32)
+    for b, (sg, seed) in enumerate(cases):
+        like[b], idx[b] = v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, float(sg), int(seed))
+    d, it, sy = dec.v2_decode_batch(like, idx)
+    for b in range(B):
+        m = [int(x) for x in g["meta"][b]]
+        assert (int(it[b]), int(sy[b]), orc.crc32(d[b].astype(np.uint8))) == (m[0], m[1], m[2]), (b, cases[b], int(it[b]), m[0])
+        st = dec.v2_state(b)
+        assert [orc.crc32(st[k]) for k in STATE] == m[3:], (b, cases[b])
+    dec.close()
