@@ -68,7 +68,13 @@ int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *pr
 void ems_destroy(ems_handle *h);
 int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */
 
-/* ---- the hot path, batched.  B <= max_batch frames.  Host-pointer variants copy in/out. ---- */
+/* ---- the hot path, batched.  B <= max_batch frames.  Host-pointer variants copy in/out. ----
+ * Every handle owns one HIP stream.  ems_llr_init*, ems_source_draw and ems_decode only queue work on it and
+ * return (keep a host buffer handed to ems_llr_init untouched until the next waiting call on the handle: with
+ * pinned memory the copy is asynchronous too); ems_get_results,
+ * ems_count_errors*, the ems_get_* inspectors and ems_synchronize wait for that stream only.  Several handles
+ * therefore run concurrently on one device -- the way the harness overlaps the tail of an early-exit batch with
+ * the next batches.  A handle is not thread-safe; use one host thread per handle. */
 
 /* channel.c:66-76 (GF(q) LLR of every symbol of every variable node) -> APP (NB_LDPC.c:281-288).
  * noisy: [B][N][logGF] float BPSK+AWGN observations (host-generated so the drand48 stream is kept). */

@@ -442,7 +442,7 @@ def test_c_harness_first_frame_offset(pkg, kat, tmp_path):
         assert tr == want
 
 
-@pytest.mark.parametrize("case,batch", [("L4", 512), ("L3a", 128), ("L3b", 64)])
+@pytest.mark.parametrize("case,batch", [("L4", 512), ("L4b", 256), ("L4c", 500), ("L3a", 128), ("L3b", 64), ("L1", 100)])
 def test_c_harness_full_operating_point_run(pkg, tmp_path, case, batch):
     """Complete Monte-Carlo points of the 64800-bit codes (several hundred full-size frames each; L4 runs to the 40th
     erroneous frame of the headline code at 2.0 dB): the GPU harness prints the trace the real reference executable
