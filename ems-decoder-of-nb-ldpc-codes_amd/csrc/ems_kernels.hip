@@ -1404,6 +1404,20 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     // its HBM round trip runs under the elementary steps
     float x[G::EPL];
     load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q, rl, x);
+    // ... and so is the OTHER C->V message of the node where this visit closes the node's sweep (APP below): it was
+    // written by an earlier visitor, a predecessor of this task, so it is final now
+    const int dst = P.t_dst[task * C.dc + t];
+    const bool lastv = rowact && P.t_last[task * C.dc + t] != 0;
+    constexpr int NPRE = (EMS_MAX_NM + LPE - 1) / LPE;
+    float ov[NPRE];
+    int og[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int k = rl + j * LPE;
+        const bool need = lastv && k < nm;
+        og[j] = need ? (int)f_ctovi[(unsigned)(dst * nm + k)] : -1;
+        ov[j] = need ? f_ctov[(unsigned)(dst * nm + k)] : 0.0f;
+    }
 
     // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
     EmsEntry *inl = lists + t * nmp;
@@ -1456,20 +1470,17 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
         }
     }
 
-    const int dst = P.t_dst[task * C.dc + t];
     // ---- ComputeAPPLog + Decision (:1887-1921, :1961-1975) of my edge's variable node when this is its last visit of
     //      the sweep: both C->V messages of the node are final then (the other one was written by the earlier visitor,
     //      a predecessor of this task).  APP = (likelihood + TMP[first edge]) + TMP[this edge], TMP = -offset except at
     //      the listed symbols.  The APP rows themselves are stored once, by app_decide_v2 when the decode ends. ----
-    const bool lastv = rowact && P.t_last[task * C.dc + t] != 0;
     if (__ballot(lastv) != 0ull) {
         float a[G::EPL], c[G::EPL];
         fill_row<Q, LPE>(drow, rl, -C.offset);
         wave_lds_sync();
-        for (int k = rl; k < nm; k += LPE) {
-            const int g = f_ctovi[(unsigned)(dst * nm + k)];
-            if (lastv && g >= 0) drow[g] = f_ctov[(unsigned)(dst * nm + k)];
-        }
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (og[j] >= 0) drow[og[j]] = ov[j];             // (og = -1 where not needed or "index -1")
         wave_lds_sync();
         load_row<Q, LPE>(drow, rl, c);
 #pragma unroll
