@@ -1408,6 +1408,7 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     // written by an earlier visitor, a predecessor of this task, so it is final now
     const int dst = P.t_dst[task * C.dc + t];
     const bool lastv = rowact && P.t_last[task * C.dc + t] != 0;
+    const float hint = f_hint[(unsigned)edge];               // search start of the selection at the end of the visit
     constexpr int NPRE = (EMS_MAX_NM + LPE - 1) / LPE;
     float ov[NPRE];
     int og[NPRE];
@@ -1523,7 +1524,6 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     wave_lds_sync();
     bool big = false;
     float T_sel = __builtin_inff();
-    const float hint = f_hint[(unsigned)edge];
     if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
     }
