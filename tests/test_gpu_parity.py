@@ -455,3 +455,18 @@ def test_c_harness_full_operating_point_run(pkg, tmp_path, case, batch):
                       batch, str(tmp_path))
     assert len(tr) == len(k["trace"]) and (tr[-1][0] == 40 or len(tr) == k["frames"])
     assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
+
+
+@pytest.mark.parametrize("inflight", [1, 2, 4])
+def test_c_harness_trace_independent_of_handles_in_flight(pkg, kat, tmp_path, inflight):
+    """EMS_INFLIGHT only changes how many batches overlap on the GPU, never the reported trace (K2, batch 16)."""
+    k = kat["K2"]
+    os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
+    out = subprocess.run([pkg.SIM_PATH] + [str(a) for a in (k["frames"], k["NbIterMax"], os.path.join(MAT, "KN_N96_K48_GF64.txt"), k["EbN"],
+                                                          k["nm"], k["offset"], k["NbOper"])], cwd=str(tmp_path),
+                         env=dict(os.environ, EMS_BATCH="16", EMS_INFLIGHT=str(inflight)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    tr = [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
+          re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", out.stdout.decode("latin-1"))]
+    assert tr == [list(t) for t in k["trace"]]
