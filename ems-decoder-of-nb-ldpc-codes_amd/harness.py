@@ -184,7 +184,7 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
                 return d.count_errors_resident(count), synd, iters
             return collect
     else:
-        inflight = 1
+        inflight = max(1, int(inflight))               # the stand-in decodes at once; its results are still tallied `inflight` rounds later
 
         def submit(slot, noisy, sigma, cws):
             res = decode_fn(noisy, sigma, cws)

@@ -16,6 +16,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 def main():
     matrix, nframes, itmax, ebn, nm, off, nop, batch, max_err = sys.argv[1:10]
+    inflight = int(sys.argv[10]) if len(sys.argv) > 10 else 3
     nframes, itmax, nm, nop, batch, max_err = int(nframes), int(itmax), int(nm), int(nop), int(batch), int(max_err)
     ebn, off = float(ebn), float(off)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -33,7 +34,7 @@ def main():
         return np.array(nberr), np.array(synd), np.array(iters)
 
     cnt, rounds = harness.monte_carlo(matrix, nframes, itmax, ebn, nm, off, nop, batch=batch, decode_fn=decode_fn,
-                                      max_err_frames=max_err)
+                                      max_err_frames=max_err, inflight=inflight)
     if not dist.is_initialized() or dist.get_rank() == 0:
         print("TRACE " + json.dumps({"trace": cnt.trace, "rounds": rounds, "nb": cnt.nb}))
     if dist.is_initialized():

@@ -39,6 +39,8 @@ def test_two_ranks_reproduce_reference_trace(kat, name, batch):
     two = _run(2, args)
     assert [list(t) for t in two["trace"]] == [list(t) for t in k["trace"]]
     assert two["rounds"] == -(-k["frames"] // (2 * batch))
+    for inflight in (1, 2):                                  # rounds launched ahead of their tally (default 3) change nothing
+        assert _run(2, args + [inflight])["trace"] == two["trace"]
 
 
 def test_truncation_at_error_budget_matches_single_rank():
@@ -48,3 +50,4 @@ def test_truncation_at_error_budget_matches_single_rank():
     two = _run(2, args)
     assert one["trace"] == two["trace"] and one["nb"] == two["nb"] < 200
     assert one["trace"][-1][0] == 3
+    assert _run(2, args + [1])["trace"] == two["trace"]     # a round launched ahead of the stop is dropped
