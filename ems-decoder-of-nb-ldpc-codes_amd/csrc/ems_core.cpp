@@ -180,10 +180,10 @@ struct ems_handle {
     int device = 0, max_batch = 0, nm_alloc = 0, n_cu = 0;
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
-    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp;
+    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;   // iso_vn: variable nodes no check node touches
     std::vector<uint8_t> cn_lh, i2b, b2i;
     CnSchedule cs;
-    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp;
+    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp, d_iso_vn;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
@@ -400,7 +400,7 @@ void ems_destroy(ems_handle *h)
     h->d_scratch.release(); h->d_stamps.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
-    h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release();
+    h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -441,6 +441,14 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     h->cn_lh.resize(E);
     for (long e = 0; e < E; ++e) h->cn_lh[e] = (uint8_t)(c->coef[e] - 1);
     if ((r = level_schedule(c, h->lvl_ptr, h->lvl_cn))) return bail(r);
+    {   // Hard decisions are written by the check-node visits; a variable node outside every check (column degree 0)
+        // keeps its channel APP for the whole decode, so Decision (tools.c:312) gives the same symbol every sweep: it is
+        // decided once, right after the LLR init (k_decide_rows).
+        std::vector<char> touched(h->N, 0);
+        for (long e = 0; e < E; ++e) touched[c->col[e]] = 1;
+        for (int n = 0; n < h->N; ++n)
+            if (!touched[n]) h->iso_vn.push_back(n);
+    }
     // Task descriptors in level order; per edge the task index of the previous visitor (reference order)
     // of its variable node within the same sweep.
     {
@@ -496,7 +504,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     const size_t B = (size_t)max_batch;
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
-        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))
@@ -531,6 +539,7 @@ int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B)
     if (!noisy_dev) return fail(EMS_EINVAL, "null noisy pointer");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(ems_launch_llr_init(noisy_dev, sigma, h->logq, h->q, (size_t)B * h->N * h->q, h->d_i2b.p, h->d_b2i.p, h->d_app.p, h->stream));
+    if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
     return EMS_OK;
@@ -551,6 +560,7 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
     if (r) return r;
     if (!llr_host) return fail(EMS_EINVAL, "null llr pointer");
     HIP_TRY(hipMemcpyAsync(h->d_app.p, llr_host, (size_t)B * h->N * h->q * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return EMS_OK;
 }
@@ -595,6 +605,17 @@ int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd)
     if (synd) HIP_TRY(hipMemcpyAsync(synd, h->d_synd.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < tmp.size(); ++i) decide[i] = tmp[i];
+    // The decode kernels store iters = -1 for a frame whose dependency wait gave up (a bounded spin that never
+    // trips unless the schedule is broken): such a frame ran on unsynchronised inputs, so the batch is refused.
+    std::vector<int> it_chk;
+    const int *itp = iters;
+    if (!itp) {
+        it_chk.resize((size_t)B);
+        HIP_TRY(hipMemcpy(it_chk.data(), h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+        itp = it_chk.data();
+    }
+    for (int b = 0; b < B; ++b)
+        if (itp[b] < 0) return fail(EMS_EHIP, "frame %d: a check-node visit gave up waiting for its predecessors (results invalid)", b);
     return EMS_OK;
 }
 
@@ -734,7 +755,8 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov)
         if ((r = h->d_scratch.alloc(n))) return r;
     }
     const int rb = ems_rec_bytes(h->nm_alloc);
-    HIP_TRY(ems_launch_expand_ctov(h->d_ctov.p + (size_t)frame * h->E * rb, rb, h->nm_alloc, h->q, h->E, h->d_scratch.p, h->stream));
+    // records are strided by the create-time nm, their fields are laid out for the current nm (refresh_plan)
+    HIP_TRY(ems_launch_expand_ctov(h->d_ctov.p + (size_t)frame * h->E * rb, rb, h->prm.nm, h->q, h->E, h->d_scratch.p, h->stream));
     HIP_TRY(hipMemcpyAsync(ctov, h->d_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return EMS_OK;
@@ -827,6 +849,7 @@ int ems_v2_reinit(ems_handle *h, int B)
     int r = check_batch(h, B);
     if (r) return r;
     if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
+    if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
                                h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
@@ -840,6 +863,7 @@ int ems_v2_decode(ems_handle *h, int B)
     int r = check_batch(h, B);
     if (r) return r;
     if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
+    if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     EmsPlan P = h->plan;
     shape_for_batch(h, B, P);                                           // 4-wave workgroups, 3 frames per CU, for big batches
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
@@ -857,6 +881,7 @@ int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *c
     int r = check_batch(h, frame + 1);
     if (r) return r;
     if (frame < 0 || !h->v2_ready) return fail(EMS_EINVAL, "bad argument");
+    if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ne = (size_t)h->E * h->nm_alloc, off = (size_t)frame * ne;
     if (vtoc) HIP_TRY(hipMemcpy(vtoc, h->d_v2_vtoc.p + off, ne * sizeof(float), hipMemcpyDeviceToHost));
@@ -908,14 +933,15 @@ int ems_debug_dump(ems_handle *h)
     return EMS_OK;
 }
 
-/* developer diagnostics (EMS_STAMPS builds): zero / read the 16 per-phase cycle accumulators */
-int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset)
+/* developer diagnostics (EMS_STAMPS builds): zero / read the 16 per-phase cycle accumulators (out24[0..15]) and the
+ * 8 event counters (out24[16..23]); the caller's buffer holds 24 values */
+int ems_debug_stamps(ems_handle *h, unsigned long long *out24, int reset)
 {
     if (!h) return fail(EMS_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (out16) HIP_TRY(hipMemcpy(out16, h->d_stamps.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (out16) HIP_TRY(ems_debug_counters(out16 + 16, reset));   /* out16 really has 24 slots: 16 stamps + 8 counters */
+    if (out24) HIP_TRY(hipMemcpy(out24, h->d_stamps.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out24) HIP_TRY(ems_debug_counters(out24 + 16, reset));
     if (reset) HIP_TRY(hipMemset(h->d_stamps.p, 0, 16 * sizeof(unsigned long long)));
     return EMS_OK;
 }
@@ -960,7 +986,11 @@ int ems_elementary_step(int GF, int nm, int nbOper, const float *in1, const floa
     if (nm < 5 || nm > EMS_MAX_NM || nbOper < 1) return fail(EMS_EINVAL, "nm outside [5,%d] or nbOper < 1", EMS_MAX_NM);
     uint8_t i2b[256], b2i[256];
     int r = gf_build(GF, i2b, b2i);
-    if (r || (r = select_device(device))) return r;
+    if (r) return r;
+    for (int k = 0; k < nm; ++k)                                  // the kernels index q-entry tables with these
+        if (idx1[k] < -1 || idx1[k] >= GF || idx2[k] < -1 || idx2[k] >= GF)
+            return fail(EMS_EINVAL, "symbol index %d outside {-1, 0..GF-1}", idx1[k] < -1 || idx1[k] >= GF ? idx1[k] : idx2[k]);
+    if ((r = select_device(device))) return r;
     Tmp t;
     float *d1 = t.up(in1, nm), *d2 = t.up(in2, nm), *dout = t.up<float>(nullptr, nm);
     int *di1 = t.up(idx1, nm), *di2 = t.up(idx2, nm), *dio = t.up<int>(nullptr, nm);
@@ -980,9 +1010,12 @@ int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *
     uint8_t i2b[256], b2i[256];
     CnSchedule cs;
     int r = gf_build(GF, i2b, b2i);
-    if (r || (r = build_cn_schedule(dc, cs)) || (r = select_device(device))) return r;
+    if (r || (r = build_cn_schedule(dc, cs))) return r;
     for (int t = 0; t < dc; ++t)
         if (coef[t] < 1 || coef[t] >= GF) return fail(EMS_EINVAL, "coefficient %d out of range", coef[t]);
+    for (int i = 0; i < dc * nm; ++i)                              // the kernel indexes q-entry tables with these
+        if (vtoc_gf[i] < -1 || vtoc_gf[i] >= GF) return fail(EMS_EINVAL, "symbol index %d outside {-1, 0..GF-1}", vtoc_gf[i]);
+    if ((r = select_device(device))) return r;
     Tmp t;
     int *dcoef = t.up(coef, dc), *dg = t.up(vtoc_gf, (size_t)dc * nm);
     float *dl = t.up(vtoc_llr, (size_t)dc * nm), *dout = t.up<float>(nullptr, (size_t)dc * GF);

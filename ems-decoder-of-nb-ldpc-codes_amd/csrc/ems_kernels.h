@@ -27,6 +27,7 @@ hipError_t ems_launch_es_unit(const float *in1, const float *in2, const int *idx
                               hipStream_t st);
 hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vtoc_llr, const int *vtoc_gf, float *ctov,
                               hipStream_t st);
+hipError_t ems_launch_decide_rows(const float *app_dev, const int *rows_dev, int nrows, int B, int N, int q, uint8_t *decide_dev, hipStream_t st);
 hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide, hipStream_t st);
 hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const int *coef, int M, int q, const int *decide,
                                     const uint8_t *idx2bin, const uint8_t *bin2idx, unsigned *first_bad, hipStream_t st);

@@ -1950,6 +1950,30 @@ __global__ void k_decision_unit(const float *__restrict__ app, int N, int q, int
     if (lane == 0) decide[n] = lv < EMS_SENTINEL ? lg : 0;
 }
 
+// Decision (tools.c:312-330) for a list of variable nodes of every frame, into the decoder's u8 decision block: the
+// variable nodes that no check node touches (their APP is the channel LLR for the whole decode).
+__global__ void k_decide_rows(const float *__restrict__ app, const int *__restrict__ rows, int nrows, int N, int q,
+                              uint8_t *__restrict__ decide)
+{
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    if (r >= nrows) return;
+    const int n = rows[r];
+    const float *a = app + ((size_t)f * N + n) * q;
+    float lv = EMS_SENTINEL;
+    int lg = 0x7FFFFFFF;
+    for (int g = lane; g < q; g += 64) {
+        const float v = a[g];
+        if (v < lv) { lv = v; lg = g; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(lv, o);
+        const int og = __shfl_xor(lg, o);
+        if (ov < lv || (ov == lv && og < lg)) { lv = ov; lg = og; }
+    }
+    if (lane == 0) decide[(size_t)f * N + n] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
+}
+
 __global__ void k_syndrome_unit(const int *__restrict__ row_ptr, const int *__restrict__ col, const int *__restrict__ coef,
                                 int M, int q, const int *__restrict__ decide, const uint8_t *__restrict__ idx2bin,
                                 const uint8_t *__restrict__ bin2idx, unsigned *first_bad)
@@ -2073,6 +2097,13 @@ hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vt
 hipError_t ems_launch_decision_unit(const float *app, int N, int q, int *decide, hipStream_t st)
 {
     hipLaunchKernelGGL(k_decision_unit, dim3((N + 3) / 4), dim3(256), 0, st, app, N, q, decide);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_decide_rows(const float *app_dev, const int *rows_dev, int nrows, int B, int N, int q, uint8_t *decide_dev,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decide_rows, dim3((nrows + 3) / 4, B), dim3(256), 0, st, app_dev, rows_dev, nrows, N, q, decide_dev);
     return hipGetLastError();
 }
 

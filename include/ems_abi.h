@@ -87,7 +87,9 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B);
 int ems_decode(ems_handle *h, int B);
 
 /* Results of the last ems_decode: decide [B][N] (tools.c:312), iters [B] = iter+1 (NB_LDPC.c:474),
- * synd [B] = value Syndrom() returns (tools.c:284).  Any pointer may be NULL. */
+ * synd [B] = value Syndrom() returns (tools.c:284).  Any pointer may be NULL.
+ * Returns EMS_EHIP (and the outputs must not be used) if the kernel flagged a frame whose dependency wait gave up
+ * -- the device marks such a frame with iters = -1; it cannot happen with a schedule built by ems_create. */
 int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd);
 
 /* llr_init + decode + get_results in one call (what Decoding() and the harness use). */
@@ -169,9 +171,9 @@ float ems_last_decode_ms(const ems_handle *h);
 void *ems_noisy_dev_ptr(ems_handle *h);
 void *ems_stream(ems_handle *h);
 int ems_synchronize(ems_handle *h);
-/* Developer diagnostics: per-phase cycle accumulators of builds compiled with -DEMS_STAMPS (all zero
- * in the product build). */
-int ems_debug_stamps(ems_handle *h, unsigned long long *out16, int reset);
+/* Developer diagnostics of builds compiled with -DEMS_STAMPS (all zero in the product build): out24 receives
+ * 24 values -- [0..15] per-phase cycle accumulators, [16..23] event counters. */
+int ems_debug_stamps(ems_handle *h, unsigned long long *out24 /*[24]*/, int reset);
 const char *ems_last_error(void);
 const char *ems_version(void);
 

@@ -230,3 +230,23 @@ def test_parameter_validation(pkg):
         with pytest.raises(pkg.EmsError) as e:
             pkg.Decoder(c, nm, 32, 0.3, 10, max_batch=2)
         assert e.value.code in (pkg.EMS_EINVAL, pkg.EMS_ENODEV)
+
+
+def test_unit_entry_points_validate_symbol_indices(pkg):
+    """ElementaryStep / CheckPassLogEMS index q-entry device tables with the caller's symbols: anything outside
+    {-1, 0..GF-1} is refused on the host (before a device is even looked for)."""
+    z = np.zeros(8, np.float32)
+    for bad in (16, 300, -2):
+        idx = np.arange(8)
+        idx[3] = bad
+        with pytest.raises(pkg.EmsError) as e:
+            pkg.ElementaryStep(z, z, idx, np.arange(8), 16, 8, 16)
+        assert e.value.code == pkg.EMS_EINVAL
+        with pytest.raises(pkg.EmsError) as e:
+            pkg.ElementaryStep(z, z, np.arange(8), idx, 16, 8, 16)
+        assert e.value.code == pkg.EMS_EINVAL
+        g = np.tile(np.arange(8), (4, 1))
+        g[2, 5] = bad
+        with pytest.raises(pkg.EmsError) as e:
+            pkg.CheckPassLogEMS(np.array([1, 2, 3, 4]), np.zeros((4, 8), np.float32), g, 16, 16, 0.3)
+        assert e.value.code == pkg.EMS_EINVAL

@@ -175,6 +175,26 @@ def test_decode_full_alist_code_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "KN_N64800_K48600_GF256_fullalist.txt", 20, 40, 0.3, 8, 3.4, 1, state=True)
 
 
+def test_isolated_variable_node_is_decided_from_its_channel_llr(pkg, orc, tmp_path):
+    """A column of degree 0: no check-node visit writes its decision; Decision (tools.c:312) reads its channel APP."""
+    src = open(os.path.join(MAT, "N96_K48_GF64")).read().split()
+    N, M, q = map(int, src[:3])
+    T = src[3:]
+    p = tmp_path / "iso.txt"
+    p.write_text("%d %d %d\n%s\n%s\n%s\n" % (N + 1, M, q, " ".join(T[:N] + ["0"]), " ".join(T[N:N + M]), " ".join(T[N + M:])))
+    o = orc.Oracle(str(p))
+    sigma = o.sigma(2.0)
+    rng = orc.Rng(0)
+    frames = [o.draw_frame(rng, sigma) for _ in range(6)]
+    noisy = np.stack([f[1] for f in frames])
+    dec = pkg.Decoder(pkg.Code(str(p)), 16, 32, 0.3, 10, max_batch=6)
+    decide, iters, synd = dec.decode_batch(noisy, sigma)
+    for b in range(6):
+        ref = o.decode(o.llr(noisy[b], sigma), 16, 32, 0.3, 10)
+        assert (decide[b] == ref["decide"]).all() and iters[b] == ref["iters"] and synd[b] == ref["synd"]
+    dec.close()
+
+
 def test_unsupported_configurations_fail_loudly(pkg):
     code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
     with pytest.raises(pkg.EmsError) as e:
