@@ -180,10 +180,12 @@ struct ems_handle {
     int device = 0, max_batch = 0, nm_alloc = 0, n_cu = 0;
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
-    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;   // iso_vn: variable nodes no check node touches
+    std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
+    std::vector<int> p_cn, p_vn, p_lh, p_pred;   // check nodes in pairs (k_decode_dual), see build_pairs
+    int n_pairs = 0;   // iso_vn: variable nodes no check node touches
     std::vector<uint8_t> cn_lh, i2b, b2i;
     CnSchedule cs;
-    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp, d_iso_vn;
+    DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp, d_iso_vn, d_p_cn, d_p_vn, d_p_lh, d_p_pred;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch;
@@ -210,6 +212,55 @@ struct ems_handle {
 
 namespace {
 
+// Pairs for the two-visits-per-wave kernel (dc = 4).  Walking the task list (dependency order), the first task not yet
+// placed opens a pair; its partner is the next unplaced task, within a short window, whose predecessors all sit in
+// EARLIER pairs (so it depends neither on the opener nor on anything still unplaced).  Pair i then depends only on
+// pairs < i, which is all the claim-in-order scheduler of the kernel needs.  The headline code gives 2026 pairs for its
+// 4050 check nodes (2 of them single) and a critical path of 460 pairs per sweep against 439 visits.
+void build_pairs(ems_handle *h)
+{
+    const int M = h->M, dc = h->dc;
+    std::vector<int> pair_of(M, -1);
+    std::vector<std::pair<int, int>> pairs;
+    int ptr = 0;
+    const int window = 64;
+    while (true) {
+        while (ptr < M && pair_of[ptr] >= 0) ++ptr;
+        if (ptr >= M) break;
+        const int a = ptr, pi = (int)pairs.size();
+        int b = -1;
+        for (int cand = a + 1; cand < std::min(M, a + 1 + window) && b < 0; ++cand) {
+            if (pair_of[cand] >= 0) continue;
+            bool ok = true;
+            for (int k = 0; k < dc && ok; ++k) {
+                const int pr = h->t_pred[(size_t)cand * dc + k];
+                ok = pr < 0 || (pair_of[pr] >= 0 && pr != a);
+            }
+            if (ok) b = cand;
+        }
+        pair_of[a] = pi;
+        if (b >= 0) pair_of[b] = pi;
+        pairs.emplace_back(a, b);
+    }
+    const int NP = (int)pairs.size();
+    h->n_pairs = NP;
+    h->p_cn.assign((size_t)NP * 2, 0); h->p_vn.assign((size_t)NP * 8, 0); h->p_lh.assign((size_t)NP * 8, 0); h->p_pred.assign((size_t)NP * 8, -1);
+    for (int i = 0; i < NP; ++i) {
+        const int a = pairs[i].first, b = pairs[i].second;
+        const int prio = std::max((h->t_cnp[a] >> 24) & 3, b >= 0 ? (h->t_cnp[b] >> 24) & 3 : 0);
+        for (int m = 0; m < 2; ++m) {
+            const int t = (m == 1 && b >= 0) ? b : a;          // a single's second half repeats the first, flagged
+            h->p_cn[(size_t)i * 2 + m] = (h->t_cnp[t] & 0xFFFFFF) | (prio << 24) | ((m == 1 && b < 0) ? (1 << 30) : 0);
+            for (int k = 0; k < dc; ++k) {
+                const size_t src = (size_t)t * dc + k, dst = (size_t)i * 8 + m * 4 + k;
+                h->p_vn[dst] = h->t_vn[src];
+                h->p_lh[dst] = h->t_lh[src];
+                h->p_pred[dst] = h->t_pred[src] < 0 ? -1 : pair_of[h->t_pred[src]];
+            }
+        }
+    }
+}
+
 int refresh_plan(ems_handle *h)
 {
     const ems_params &p = h->prm;
@@ -224,6 +275,8 @@ int refresh_plan(ems_handle *h)
     P.lvl_ptr = h->d_lvl_ptr.p; P.lvl_cn = h->d_lvl_cn.p; P.cn_vn = h->d_cn_vn.p; P.cn_lh = h->d_cn_lh.p;
     P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
     P.t_cn = h->d_t_cnp.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
+    P.n_pairs = h->n_pairs; P.dual = 0;
+    P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
@@ -401,6 +454,7 @@ void ems_destroy(ems_handle *h)
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
+    h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -498,13 +552,15 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         }
     }
 
+    if (h->dc == 4) build_pairs(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(EMS_EHIP, "hipEventCreate failed"));
     const size_t B = (size_t)max_batch;
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
-        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_p_cn.upload(h->p_cn)) || (r = h->d_p_vn.upload(h->p_vn)) ||
+        (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))
@@ -570,13 +626,23 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
 // kernels run several 4-wave workgroups per CU instead (one wave of every workgroup on each SIMD; a 6-wave
 // workgroup would not spread evenly and two of them cannot share a CU): 3 frames per CU with the ~143-VGPR
 // build, 4 with the 128-VGPR build where it exists and the batch fills it.  Other kernels keep the plan's shape.
-static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P)
+static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_dual = true)
 {
     P.occ4 = 0;
-    if (getenv("EMS_WAVES")) { P.occ4 = getenv("EMS_OCC4") ? 1 : 0; return; }     // developer knobs
+    P.dual = 0;
+    auto go_dual = [&](int waves) {
+        P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, P.nm);
+    };
+    // developer knobs: EMS_DUAL=<waves per workgroup> forces the two-visits-per-wave kernel, EMS_DUAL=0 forbids it
+    const char *ed = getenv("EMS_DUAL");
+    if (allow_dual && ed && atoi(ed) > 0 && ems_has_dual_kernel(P)) { go_dual(std::min(4, atoi(ed))); return; }
+    if (getenv("EMS_WAVES")) { P.occ4 = getenv("EMS_OCC4") ? 1 : 0; return; }
     if (ems_max_waves_for(h->dc) != 12 || P.waves_per_wg < 12 || h->n_cu <= 0) return;
     const size_t lds_cap = 160 * 1024, wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
+    // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
+    if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 5 && ems_has_dual_kernel(P) &&
+        6 * ems_dual_wg_lds_bytes(h->q, P.nm, P.n_pairs, 2) <= lds_cap) { go_dual(2); return; }
     if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
     else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }
@@ -784,7 +850,7 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf)
 // ------------------------------------------------------------------------------------------------
 // v2 flavour (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c): same handle, own state.
 // ------------------------------------------------------------------------------------------------
-static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P);
+static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_dual);
 static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
@@ -865,7 +931,7 @@ int ems_v2_decode(ems_handle *h, int B)
     if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
     if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     EmsPlan P = h->plan;
-    shape_for_batch(h, B, P);                                           // 4-wave workgroups, 3 frames per CU, for big batches
+    shape_for_batch(h, B, P, false);                                    // 4-wave workgroups, 3 frames per CU, for big batches
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
     P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;

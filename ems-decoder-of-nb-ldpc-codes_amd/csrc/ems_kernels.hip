@@ -146,7 +146,7 @@ __device__ __forceinline__ unsigned sym_comb(unsigned a, unsigned b)
 // starts at (4, p-4) and walks down (:548-551).  Each lane keeps its own head (value + packed symbol)
 // and prefetches its next cell, so the only per-step cross-lane traffic is three 8-lane butterflies.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, int a_id, int b_id, int o_id,
+__device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, int a_id, int b_id, int o_id, int l_id,
                                          int nm, int nbOper)
 {
     const int p = lane & 7;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void es_stage(EmsEntry *lists, int *lens, int lane, i
             nx = mv[min(pos + 1, nm - 1)];
         }
     }
-    if (has && p == 0) lens[o_id] = s;
+    if (has && p == 0) lens[l_id] = s;   // l_id: the output's slot in lens (= o_id except in the two-visit layout)
 }
 
 
@@ -235,12 +235,22 @@ __device__ __forceinline__ unsigned red8_minu(unsigned x)
 // Register-light form of es_post for the rare continuation (T up to 64 picks): same algorithm, the
 // per-pick value/symbol are recomputed in each of the three passes instead of being kept in registers.
 // (p, gbase: lane within / first lane of the task's 16 lanes.)
-template <int FL = 0>
+// min over the TL (8 or 16) lanes of a task
+template <int TL> __device__ __forceinline__ int redT_mini(int x)
+{
+    x = red8_mini(x);
+    if (TL == 16) x = min(x, dpp_i<DPP_MIRROR>(x));
+    return x;
+}
+
+// TL: lanes per task (16 in the one-visit-per-wave kernels, 8 where a wave carries two visits)
+template <int FL = 0, int TL = 16>
 __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
                                            const uint8_t *picks, int q, int p, int gbase, bool has, int T, int nm,
                                            int nbOper, int &S_out)
 {
-    const int NJ = (T + 15) >> 4;
+    constexpr unsigned TMASK = (1u << TL) - 1u;
+    const int NJ = (T + TL - 1) / TL;
     auto gather = [&](int i, bool ok, float &v, unsigned &sy, int &k) {
         const unsigned pk = picks[ok ? i : 0];
         const int w = pk >> 5;
@@ -254,19 +264,19 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     wave_lds_sync();
     int lim = 1 << 20;
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         const bool ok = has && i < T;
         float v; unsigned sy; int k;
         gather(i, ok, v, sy, k);
         const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
         lim = min(lim, li);
     }
-    lim = red16_mini(lim);
+    lim = redT_mini<TL>(lim);
     const bool stopped = lim <= T;
     lim = min(lim, T);
     wave_lds_sync();
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         if (has && i < lim) atomicMax(&tbl[sy & 0xFFu], (unsigned)(ES_MAX_STEPS - i));
@@ -274,18 +284,18 @@ __device__ __forceinline__ bool es_post_rt(const EmsEntry *in1, const EmsEntry *
     wave_lds_sync();
     int base = 0;
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         const bool u = has && i < lim && tbl[sy & 0xFFu] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & TMASK;
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{v, sy & 0xFFu};
         base += __popc(m8);
     }
     wave_lds_sync();
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         float v; unsigned sy; int k;
         gather(i, has && i < T, v, sy, k);
         if (has && i < lim) tbl[sy & 0xFFu] = 0u;
@@ -375,7 +385,7 @@ __device__ __forceinline__ void es_merge(unsigned &hv, int &y, float fxv, const 
 // one stage in ten at nm = 20: duplicates eat picks), the merge runs 8 more steps with the exact rule and the
 // new picks go through the same table incrementally -- its first-pass claims are still in place, and a later
 // pick never displaces an earlier one (ds_max of ES_MAX_STEPS - i).  tbl is all-zero on entry and on exit.
-template <int NJ, int FL = 0>
+template <int NJ, int FL = 0, int TL = 16>
 __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2, EmsEntry *out, unsigned *tbl,
                                         uint8_t *picks, uint8_t *dummy, int q, int p, int gbase, int p8, int gbase8, bool has, int T, int nm,
                                         int nbOper, int &S_out, unsigned &hv, int &y, float fxv, const EmsEntry *mvy, int &T_done)
@@ -397,27 +407,27 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     };
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         int li;
         gather(i, has && i < T, val[j], sym[j], li);
         lim = min(lim, li);
     }
-    lim = red16_mini(lim);
+    lim = redT_mini<TL>(lim);
     bool stopped = lim <= T;
     lim = min(lim, T);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         if (has && i < lim) atomicMax(&tbl[sym[j]], (unsigned)(ES_MAX_STEPS - i));
     }
     wave_lds_sync();
     int base = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int i = p + 16 * j;
+        const int i = p + TL * j;
         const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & ((1u << TL) - 1u);
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
         base += __popc(m8);
@@ -437,14 +447,14 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
         float v;
         int li;
         gather(i, ok, v, symx, li);
-        int lim2 = red16_mini(li);
+        int lim2 = redT_mini<TL>(li);
         const bool stopped2 = lim2 <= T2;
         lim2 = min(lim2, T2);
         clrx = ok && i < lim2;
         if (clrx) atomicMax(&tbl[symx], (unsigned)(ES_MAX_STEPS - i));
         wave_lds_sync();
         const bool u = clrx && tbl[symx] == (unsigned)(ES_MAX_STEPS - i);
-        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & 0xFFFFu;
+        const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & ((1u << TL) - 1u);
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{v, symx};
         if (!done) {
@@ -455,22 +465,23 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-        if (has && p + 16 * j < lim) tbl[sym[j]] = 0u;
+        if (has && p + TL * j < lim) tbl[sym[j]] = 0u;
     if (clrx) tbl[symx] = 0u;
     S_out = min(base, nm);
     return done;
 }
 
+template <int TL = 16>
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
                                               int lane, uint2 task, int nm, int nbOper, int T1)
 {
-    // A task owns 16 lanes.  The merge needs 8 (its 8 competitors): both halves run it identically (same inputs,
-    // same picks written to the same bytes); the post-pass then spreads the picks over all 16 lanes.
+    // A task owns TL lanes.  The merge needs 8 (its 8 competitors): with TL = 16 both halves run it identically (same
+    // inputs, same picks written to the same bytes); the post-pass then spreads the picks over all TL lanes.
     const int p = lane & 7;                         // competitor
     const int gbase = lane & ~7;
-    const int p16 = lane & 15;                      // post-pass lane
-    const int gbase16 = lane & ~15;
-    const int gsel = lane >> 4;
+    const int p16 = lane & (TL - 1);                // post-pass lane
+    const int gbase16 = lane & ~(TL - 1);
+    const int gsel = lane / TL;
     const bool has = (task.y >> 16) != 0u;          // see es_task(): byte offsets of the lists, output id + 1
     const int o_id = (int)(task.y >> 16) - 1;
     const int nmp = list_stride(nm);
@@ -484,7 +495,7 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 
     if (has) {
 #pragma unroll 3
-        for (int k = p16; k < nmp; k += 16) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
+        for (int k = p16; k < nmp; k += TL) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
     }
 
     const bool rowc = p < 4;
@@ -510,14 +521,16 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
     int Td = T1;   // picks merged so far
-    if (T1 <= 16) done = es_post<1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else if (T1 <= 32) done = es_post<2>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else done = es_post_rt(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
+    if (T1 <= TL) done = es_post<1, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (T1 <= 2 * TL) done = es_post<2, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (TL == 8 && T1 <= 24) done = es_post<3, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (TL == 8 && T1 <= 32) done = es_post<4, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else done = es_post_rt<0, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
         // rare: neither nm outputs nor a stop within the first nm+3 (+8) picks -> merge on up to nbOper
         DBG_ADD(6, 1);
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
-        es_post_rt(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
+        es_post_rt<0, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
     }
     if (has && p16 == 0) lens[o_id] = S;
 }
@@ -564,25 +577,51 @@ __device__ __forceinline__ uint2 cn_task(int dc, int nmp, int t, int grp)
     else if (grp == 3 && kb >= 0) { a = list_P(dc, kb); b = list_S(dc, kb + 2); o = list_M(dc, kb); }
     return es_task(a, b, o, nmp);
 }
+// Two visits per wave (k_decode_dual, dc = 4): the wave's list area holds the four input lists of visit 0, the four of
+// visit 1, then the six other lists (prefix, suffix, merges) of visit 0 and of visit 1 -- the selection's survivor
+// scratch aliases everything behind the inputs, which is dead until the elementary steps start.  Offsets in entries.
+constexpr int DUAL_DC = 4, DUAL_NLISTS = DUAL_DC + 3 * (DUAL_DC - 2);
+__host__ __device__ inline int dual_list_off(int half, int id, int nmp)
+{
+    return id < DUAL_DC ? (half * DUAL_DC + id) * nmp : (2 * DUAL_DC + half * (DUAL_NLISTS - DUAL_DC) + (id - DUAL_DC)) * nmp;
+}
+// task of 8-lane group grp (visit grp >> 2, task grp & 3) in stage t
+__device__ __forceinline__ uint2 cn_task_dual(int nmp, int t, int grp)
+{
+    const int half = grp >> 2, dc = DUAL_DC;
+    const uint2 tk = cn_task(dc, 1, t, grp & 3);                 // nmp = 1: offsets / 8 = list ids
+    if ((tk.y >> 16) == 0u) return uint2{0u, 0u};
+    const int a = (int)(tk.x & 0xFFFFu) / 8, b = (int)(tk.x >> 16) / 8, o = (int)(tk.y & 0xFFFFu) / 8;
+    return uint2{(unsigned)(dual_list_off(half, a, nmp) * 8) | ((unsigned)(dual_list_off(half, b, nmp) * 8) << 16),
+                 (unsigned)(dual_list_off(half, o, nmp) * 8) | ((unsigned)(half * DUAL_NLISTS + o + 1) << 16)};
+}
+__device__ __forceinline__ void cn_sched_build_dual(uint2 *sched, int nm, int tid, int nthreads)
+{
+    for (int i = tid; i < (DUAL_DC - 2) * 8; i += nthreads) sched[i] = cn_task_dual(list_stride(nm), (i >> 3) + 1, i & 7);
+}
+
 // filled once per kernel by the whole workgroup (caller synchronises)
 __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int tid, int nthreads)
 {
     for (int i = tid; i < (dc - 2) * 8; i += nthreads) sched[i] = cn_task(dc, list_stride(nm), (i >> 3) + 1, i & 7);
 }
 
+// TL lanes per elementary-step task: 16 (one visit per wave; the literal form uses 8 of them twice over) or 8 (two visits)
+template <int TL = 16>
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
                                         int lane, bool literal)
 {
-    const int grp = lane >> 4;                      // 16 lanes per elementary-step task (the literal form uses 8 of them twice over)
+    const int grp = lane / TL;
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= C.nsteps; ++t) {
         const uint2 task = sched[(t - 1) * 8 + grp];
-        if (fast) es_stage_fast(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
+        if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
         else {
+            // literal form: list ids from the byte offsets (es_stage takes entry pointers through ids of stride nmp)
             const int lb = list_stride(C.nm) * 8;
             const bool has = (task.y >> 16) != 0u;
             es_stage(lists, lens, lane, has ? (int)(task.x & 0xFFFFu) / lb : -1, has ? (int)(task.x >> 16) / lb : -1,
-                     has ? (int)(task.y >> 16) - 1 : -1, C.nm, C.nbOper);
+                     has ? (int)(task.y & 0xFFFFu) / lb : -1, has ? (int)(task.y >> 16) - 1 : -1, C.nm, C.nbOper);
         }
         wave_lds_sync();
     }
@@ -938,21 +977,29 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 
 // ------------------------------------------------------------------------------------------------
 // One check-node visit by one wave: NB_LDPC.c:329-450 around bubble_decoder.c:72-305.
+// DUAL (dc = 4, LPE = 8): TWO visits by one wave -- edge rows 0..3 belong to the visit of check node `cn` as lanes
+// 0..31 see it, rows 4..7 to the one lanes 32..63 see; every row-wise phase serves both, and the elementary steps of
+// both (2 + 2 tasks in the first stage, 4 + 4 in the second, 8 lanes each) share one merge loop.  gact = false masks
+// the global stores of a half that has no visit of its own (it shadows the other half's inputs).
 // ------------------------------------------------------------------------------------------------
-template <int Q, int LPE>
+template <int Q, int LPE, bool DUAL = false>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                           EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane
+                                           EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane,
+                                           bool gact = true
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
                                            )
 {
     using G = Geo<Q, LPE>;
+    static_assert(!DUAL || LPE == 8, "two visits per wave: 8 rows of 8 lanes");
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
-    const bool rowact = row < C.dc;
-    const int t = rowact ? row : C.dc - 1;         // idle rows shadow the last edge, stores masked
+    const int half = DUAL ? row >> 2 : 0;
+    const bool rowact = DUAL ? true : row < C.dc;  // the row computes (LDS side)
+    const bool stact = DUAL ? gact : rowact;       // ... and stores its results to HBM
+    const int t = DUAL ? (row & 3) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
     const int nm = C.nm;
     const int qm1 = Q - 1;
     const int edge = cn * C.dc + t;
@@ -996,7 +1043,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(0);
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
     const int nmp = list_stride(nm);
-    EmsEntry *inl = lists + t * nmp;
+    EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp) : t * nmp);
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
     float T_sel = __builtin_inff();
     if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
@@ -1029,15 +1076,15 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     // the dense staging rows are dead until the expansion below: their first 4Q words serve as the four dedupe
     // tables of the elementary steps, zeroed here and kept all-zero from stage to stage
     unsigned *tbl = reinterpret_cast<unsigned *>(dense);
-    for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
+    for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
     wave_lds_sync();
-    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
+    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
 
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
-    const EmsEntry *ol = lists + oid * nmp;
-    const int stp = (C.dc == 2) ? nm : lens[oid];
+    const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp) : oid * nmp);
+    const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * DUAL_NLISTS + oid : oid];
     const float dflt = ol[stp - 1].v + C.offset;
     fill_row<Q, LPE>(drow, rl, dflt);
     wave_lds_sync();
@@ -1045,12 +1092,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
         const EmsEntry e = ol[k];
         const int g = gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1);
         drow[g] = e.v;
-        if (rowact) {
+        if (stact) {
             reinterpret_cast<float *>(rec)[k] = e.v;
             rec[EMS_REC_SYM(nm) + k] = (uint8_t)g;
         }
     }
-    if (rowact && rl == 0) {
+    if (stact && rl == 0) {
         *reinterpret_cast<float *>(rec + EMS_REC_HINT(nm)) = T_sel;
         *reinterpret_cast<float *>(rec + EMS_REC_DFLT(nm)) = dflt;
         rec[EMS_REC_CNT(nm)] = (uint8_t)stp;
@@ -1060,7 +1107,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     load_row<Q, LPE>(drow, rl, napp);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) napp[e] = napp[e] + mvc[e];
-    if (rowact) store_row<Q, LPE>(app_row, rl, napp);
+    if (stact) store_row<Q, LPE>(app_row, rl, napp);
 
     // ---- Decision (tools.c:312-330) of this variable node; the later visit of the sweep wins ----
     //      first strict minimum below 1e5 = the row minimum, at the lowest symbol that attains it
@@ -1069,7 +1116,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 #pragma unroll
     for (int e = G::EPL - 1; e >= 0; --e) lgu = (napp[e] == lv) ? (unsigned)G::sym_of(e, rl) : lgu;   // a lane's symbols ascend with e
     const int lg = (int)row_min_u<LPE>(lgu);
-    if (rowact && rl == 0) (P.decide + (size_t)f * P.N)[(unsigned)vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
+    if (stact && rl == 0) (P.decide + (size_t)f * P.N)[(unsigned)vn] = (uint8_t)(lv < EMS_SENTINEL ? lg : 0);
     wave_lds_sync();
     STAMP(3);
 }
@@ -1244,6 +1291,159 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
     if (lane == 0 && P.stamps)
         for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[(wave < 9 ? 0 : 8) + i], st_acc[i]);
 #endif
+    if (tid == 0) {
+        P.iters[f] = *spin_fail ? -1 : it;
+        P.synd[f] = (int)synd;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The decode kernel with TWO check-node visits per wave (dc = 4; see process_cn<.., DUAL>): the elementary steps are
+// 45 % of a visit and their serial merge loop costs the same whether 2 or 8 of the wave's 8-lane groups carry a task,
+// so a wave takes a PAIR of mutually independent check nodes and the merge loops run half as often per check node.
+// The host pairs the check nodes (ems_core.cpp, build_pairs): pair i depends only on pairs < i, claimed in that order
+// from the LDS counter like the tasks of k_decode; a pair with one member leaves rows 4..7 shadowing rows 0..3.
+// One done BIT per pair (reset between sweeps) instead of a tagged byte per task, the schedule table holds the two
+// stages only, the survivor scratch aliases the non-input lists: 12.4 KiB of LDS per wave, and 2-wave workgroups run six
+// to a CU -- 12 waves, 24 visits in flight (k_decode: 16 waves, 16 visits).
+// LDS carve: [idx2bin Q][bin2idx Q][first_bad, next_task, spin_fail, pad][schedule 2 x 8 tasks][done bits] then per
+// wave: 8 staging rows | 8 input lists | 12 other lists | lens | picks  (survivors alias from the other lists on).
+// ------------------------------------------------------------------------------------------------
+constexpr int DUAL_SCHED_BYTES = (DUAL_DC - 2) * 8 * 8;
+__host__ __device__ inline int dual_header_bytes(int q, int n_pairs) { return 2 * q + 16 + DUAL_SCHED_BYTES + (((n_pairs + 31) / 32 * 4 + 15) & ~15); }
+__host__ __device__ inline int dual_wave_bytes(int q, int nm)
+{
+    const int nmp = list_stride(nm);
+    const int other = (2 * (DUAL_NLISTS - DUAL_DC) * nmp * 8 + 2 * DUAL_NLISTS * 4 + ES_PICK_BYTES + 15) & ~15;   // other lists | lens | picks
+    const int survb = 8 * surv_stride(8) * 8;
+    return 8 * q * 4 + 2 * DUAL_DC * nmp * 8 + (other > survb ? other : ((survb + 15) & ~15));
+}
+
+template <int Q, int NM>
+__global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
+{
+    constexpr int LPE = 8;
+    Cfg C;
+    C.dc = DUAL_DC;
+    C.nm = NM > 0 ? NM : P.nm;
+    C.nbOper = P.nbOper;
+    C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
+    C.q = Q;
+    C.nsteps = DUAL_DC - 2;
+    C.n_lists = DUAL_NLISTS;
+    C.offset = P.offset;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *t_i2b = smem;
+    uint8_t *t_b2i = smem + Q;
+    unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
+    unsigned *next_task = first_bad + 1;
+    unsigned *spin_fail = first_bad + 2;
+    uint2 *sched = reinterpret_cast<uint2 *>(smem + 2 * Q + 16);
+    unsigned *done = reinterpret_cast<unsigned *>(smem + 2 * Q + 16 + DUAL_SCHED_BYTES);
+    const int NP = P.n_pairs, ndw = (NP + 31) / 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int f = blockIdx.x;
+    const int rl = lane & (LPE - 1);
+    const int row = lane / LPE;
+    const int half = row >> 2;
+    const int oid = P.out_list[row & 3];
+
+    const int nmp = list_stride(C.nm);
+    uint8_t *wbase = smem + dual_header_bytes(Q, NP) + (size_t)wave * P.wave_lds_bytes;
+    float *dense = reinterpret_cast<float *>(wbase);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + 8 * Q * 4);
+    uint8_t *other = wbase + 8 * Q * 4 + 2 * DUAL_DC * nmp * 8;
+    EmsEntry *surv = reinterpret_cast<EmsEntry *>(other);                       // dead before the elementary steps start
+    int *lens = reinterpret_cast<int *>(other + 2 * (DUAL_NLISTS - DUAL_DC) * nmp * 8);
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + 2 * DUAL_NLISTS * 4;
+
+    for (int i = tid; i < Q; i += blockDim.x) {
+        t_i2b[i] = P.idx2bin[i];
+        t_b2i[i] = P.bin2idx[i];
+    }
+    for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
+    cn_sched_build_dual(sched, C.nm, tid, blockDim.x);
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
+    __syncthreads();
+
+    int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
+    unsigned synd = 0;
+    for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
+        auto claim = [&]() {
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(next_task, 1u);
+            return (int)__builtin_amdgcn_readfirstlane((int)i);
+        };
+        int cur = claim();
+        int cnw = 0, vn = 0, lh = 0, pred = -1;
+        if (cur < NP) {
+            cnw = P.p_cn[cur * 2 + half];                      // check node | priority << 24 | (no visit of its own) << 30
+            vn = P.p_vn[cur * 8 + row];
+            lh = P.p_lh[cur * 8 + row];
+            pred = P.p_pred[cur * 8 + row];
+        }
+        while (cur < NP) {                                     // NB_LDPC.c:320, in dependency order
+            const int nxt = claim();                           // the following pair's descriptor travels under this one
+            int ncnw = 0, nvn = 0, nlh = 0, npred = -1;
+            if (nxt < NP) {
+                ncnw = P.p_cn[nxt * 2 + half];
+                nvn = P.p_vn[nxt * 8 + row];
+                nlh = P.p_lh[nxt * 8 + row];
+                npred = P.p_pred[nxt * 8 + row];
+            }
+            const bool gact = ((cnw >> 30) & 1) == 0;
+            {   // wait for the previous visitors of my variable nodes (same sweep)
+                const int pp = (rl == 0 && gact) ? pred : -1;
+                unsigned spins = 0;
+                for (;;) {
+                    const bool ok = pp < 0 || ((__hip_atomic_load(&done[pp >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (pp & 31)) & 1u) != 0u;
+                    if (__ballot(!ok) == 0ull) break;
+                    if (++spins > (1u << 24)) {                // never expected; keeps a bug from hanging the GPU
+                        if (lane == 0) atomicOr(spin_fail, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                switch ((__builtin_amdgcn_readfirstlane(cnw) >> 24) & 3) {   // static priority: the more urgent of the two (host)
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+                }
+            }
+            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact);
+            // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicOr(&done[cur >> 5], 1u << (cur & 31));
+            cur = nxt; cnw = ncnw; vn = nvn; lh = nlh; pred = npred;
+        }
+        __syncthreads();
+        if (tid == 0) *next_task = 0;
+        for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
+        // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero sum ----
+        for (int c = tid; c < P.M; c += blockDim.x) {
+            unsigned acc = 0;
+            for (int i = 0; i < DUAL_DC; ++i) {
+                const int ed = c * DUAL_DC + i;
+                const int x = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
+                acc ^= t_i2b[gf_mul_log(x, P.cn_lh[ed], Q - 1)];
+            }
+            if (acc) atomicMin(first_bad, ((unsigned)c << 8) | t_b2i[acc]);
+        }
+        __syncthreads();
+        const unsigned fb = *first_bad;
+        __syncthreads();
+        if (tid == 0) *first_bad = 0xFFFFFFFFu;
+        synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        if (synd == 0 && P.early_exit) {                       // NB_LDPC.c:470-471
+            it = sweep + 1;
+            break;
+        }
+    }
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
@@ -1880,7 +2080,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
     if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
         es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3));
-    else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nm, nbOper);
+    else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
         const EmsEntry e = lists[2 * nmp + k];
@@ -2021,6 +2221,18 @@ template <int Q, int LPE, int DC = 0, int NM = 0, bool OCC4 = false> static hipE
     return hipGetLastError();
 }
 static bool spec_ok(const EmsPlan &P) { return P.nbOper >= P.nm + 3 && P.nbOper <= 64; }
+// two-visits-per-wave build (k_decode_dual): the BASELINE headline configuration
+bool ems_has_dual_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == DUAL_DC && P.nm == 20 && P.n_pairs > 0; }
+size_t ems_dual_wave_lds_bytes(int q, int nm) { return (size_t)dual_wave_bytes(q, nm); }
+size_t ems_dual_wg_lds_bytes(int q, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, n_pairs) + (size_t)dual_wave_bytes(q, nm) * waves; }
+template <int Q, int NM> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    const size_t lds = ems_dual_wg_lds_bytes(Q, P.nm, P.n_pairs, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_dual<Q, NM>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_dual<Q, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
 // kernels that also exist in the 16-waves-per-CU build
 bool ems_has_occ4_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == 4 && P.nm == 20; }
 
@@ -2029,6 +2241,10 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
     const bool spec = spec_ok(P);
+    if (P.dual) {
+        if (!ems_has_dual_kernel(P) || P.waves_per_wg > 4 || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.nm)) return hipErrorInvalidValue;
+        return launch_decode_dual_t<256, 20>(P, B, st);
+    }
     if (P.occ4 && P.waves_per_wg <= 4 && ems_has_occ4_kernel(P)) return launch_decode_t<256, 16, 4, 20, true>(P, B, st);
     if (spec && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);
     if (spec && P.q == 64 && P.dc == 4 && P.nm == 16) return launch_decode_t<64, 16, 4, 16>(P, B, st);

@@ -344,6 +344,65 @@ def test_decode_gf256_small_workgroup_shapes_vs_oracle(pkg, orc, monkeypatch, wa
     assert list(it) == [30, 30, 30, 25]
 
 
+@pytest.mark.parametrize("waves", [2, 4, 1])
+def test_decode_gf256_two_visits_per_wave_vs_oracle(pkg, orc, monkeypatch, waves):
+    """k_decode_dual (two check nodes per wave, the shape picked for >= 5 frames per CU), forced on a batch the oracle
+    can follow: hard decisions, iterations, syndromes, the whole APP block and every C->V row, bit for bit."""
+    monkeypatch.setenv("EMS_DUAL", str(waves))
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.6, 4, state=True)
+    assert list(it) == [30, 30, 30, 25]
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 5, 0.0, 2, state=True, early_exit=False)
+
+
+def test_two_visits_per_wave_kernel_on_other_dc4_gf256_inputs(pkg, orc, monkeypatch):
+    """The literal fall-backs inside the dual kernel: noiseless frames (huge tie groups -> select_rounds) and saturated /
+    negative LLRs (the guard that sends a visit to the literal bubble loop), against the oracle."""
+    monkeypatch.setenv("EMS_DUAL", "2")
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = orc.Oracle(path)
+    rs = np.random.RandomState(5)
+    llr = np.zeros((3, o.N, 256), np.float32)
+    llr[0] = o.llr(o.draw_frame(orc.Rng(7), 0.0)[1], 0.5)                        # noiseless: few distinct values per row
+    llr[1] = (rs.randint(0, 4, size=(o.N, 256)) * 2.5).astype(np.float32)       # massive ties
+    llr[2] = rs.uniform(-50.0, 2.0e4, size=(o.N, 256)).astype(np.float32)       # negative and > 1e4 values
+    llr[2, 3, :] = 2e5                                                           # a node with nothing selectable
+    llr[2, 9, 12:] = 1e5                                                         # fewer than nm selectable symbols
+    dec = pkg.Decoder(pkg.Code(path), 20, 40, 0.3, 4, max_batch=3, early_exit=False)
+    dec.load_llr(llr)
+    dec.decode(3)
+    d, it, sy = dec.results(3)
+    for b in range(3):
+        ref = o.decode(llr[b], 20, 40, 0.3, 4, early_exit=False, want_state=True)
+        assert (d[b] == ref["decide"]).all() and sy[b] == ref["synd"] and it[b] == ref["iters"], "frame %d" % b
+        assert dec.app(b).tobytes() == ref["app"].tobytes(), "frame %d: APP differs" % b
+    dec.close()
+
+
+def test_full_size_headline_batch1536_dual_shape_agrees(pkg, orc):
+    """The bench's batch (1536 frames = 6 per CU, fixed work at 1.0 dB) takes the two-visits-per-wave kernel: frame
+    for frame it must give what the one-frame-per-CU launch gives, and the oracle's result on a sampled frame."""
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    o = orc.Oracle(path)
+    sigma = o.sigma(1.0)
+    rng = orc.Rng(0)
+    base = [o.draw_frame(rng, sigma) for _ in range(8)]
+    idx = np.arange(1536) % 8
+    noisy = np.stack([base[i][1] for i in idx])
+    code = pkg.Code(path)
+    big = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=1536, early_exit=False)
+    d, it, sy = big.decode_batch(noisy, sigma)
+    small = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=8, early_exit=False)
+    d8, it8, sy8 = small.decode_batch(noisy[:8], sigma)
+    for b in range(1536):
+        assert (d[b] == d8[b % 8]).all() and sy[b] == sy8[b % 8] and it[b] == it8[b % 8]
+    for b in (0, 5, 517, 1535):
+        assert big.app(b).tobytes() == small.app(b % 8).tobytes()
+        assert big.ctov(b).tobytes() == small.ctov(b % 8).tobytes()
+    ref = o.decode(o.llr(noisy[3], sigma), 20, 40, 0.3, 6, early_exit=False, want_state=True)
+    assert big.app(3).tobytes() == ref["app"].tobytes() and (d[3] == ref["decide"]).all()
+    big.close(); small.close()
+
+
 def test_full_size_headline_batch1024_shapes_agree(pkg, orc):
     """BASELINE batch of the bench (1024 frames = 4 per CU, fixed work at 1.0 dB): the 128-VGPR 4-wave
     launch must give, frame for frame, what the one-frame-per-CU launch gives (hard decisions, syndromes,
