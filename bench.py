@@ -7,7 +7,8 @@ A "step" is one pass of the hot path over one batch of synthetic frames per GPU:
 init -> 29 layered EMS sweeps with per-sweep hard decision + syndrome -> bit-error count, inputs
 (noisy BPSK samples + transmitted codewords) already resident in HBM.  Workload at every N is
 BASELINE.json configs[3]: Ahmed_64800_R12_GF256, nm=20, NbIterMax=30 (29 sweeps, NB_LDPC.c:314),
-offset 0.3, NbOper 40, batch 1024 per GPU (4 frames per CU), early exit disabled (fixed work),
+offset 0.3, NbOper 40, batch 1536 per GPU (6 frames per CU, the shape of the two-visits-per-wave kernel, see DESIGN.md
+sections 4.1 and 5), early exit disabled (fixed work),
 Eb/N0 = 1.0 dB frames drawn
 from the reference harness' own drand48 stream (each rank jumps the LCG to its frame range).  Frames are
 independent, so ranks share nothing on the data path ("scaling": "weak"); per step the ranks all-reduce
@@ -31,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (matrix, nm, NbOper, offset, NbIterMax, EbN0 for fixed work, default batch)
-    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1024),
+    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1536),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
     # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
@@ -39,6 +40,11 @@ WORKLOADS = {
     "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1024),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_name(workload, B, n_cu=256):
+    """The decode kernel the library launches for this workload and batch (ems_core.cpp: shape_for_batch)."""
+    return "k_decode_dual" if workload == "gf256" and (B + n_cu - 1) // n_cu >= 5 and os.environ.get("EMS_DUAL") != "0" else "k_decode"
 
 
 def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):
@@ -363,7 +369,7 @@ def main():
                        "batch_per_gpu": B, "sharding": "independent frames, contiguous batches per rank",
                        "collective": "all-reduce of 5 int64 error counters per step" if world > 1 else "none",
                        "frames_errframes_biterrs_undetected_sumiter": tot},
-            "roofline": {"bound": "hbm", "kernel": "k_decode (persistent, 1 workgroup per frame, %d frames per launch)" % B,
+            "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % (kernel_name(a.workload, B), B),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3),

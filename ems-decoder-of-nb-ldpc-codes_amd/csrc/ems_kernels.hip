@@ -133,6 +133,16 @@ __device__ __forceinline__ int gf_div_log(int g, int lh, int qm1)   // DIVGF[g][
 // walking off its list needs no bounds test: the pad makes its head +inf and it never wins again.
 __host__ __device__ inline int list_stride(int nm) { return nm + 2; }
 
+// The two-visits-per-wave kernel (k_decode_dual): its eight q-wide staging rows (8 lanes x 16 bytes per access) all
+// start on the same LDS bank, and a 16-byte wave access is served in groups of 16 lanes = pieces of four rows, two of
+// which then collide.  Rows 2, 3, 6, 7 therefore keep their 32-dword groups pairwise swapped (dword index ^ 32): the
+// four pieces of each group fall on four different quarters of the 64 banks, at no cost in space.
+#ifndef EMS_DUAL_NOSWZ
+__device__ __forceinline__ int dual_row_swz(int row) { return (row & 2) << 4; }   // 0 or 32 (dwords)
+#else
+__device__ __forceinline__ int dual_row_swz(int) { return 0; }                    // (A/B build)
+#endif
+
 __device__ __forceinline__ unsigned sym_comb(unsigned a, unsigned b)
 {
     return ((a ^ b) & 0xFFu) | ((a | b) & EMS_S_INVALID);
@@ -677,6 +687,29 @@ template <int Q, int LPE, typename PT> __device__ __forceinline__ void fill_row(
     store_row<Q, LPE>(base, rl, x);
 }
 
+// LDS staging-row forms with the index swizzle sw (0 or 32 dwords; 16-byte vectors of 8-lane rows only): vector j of
+// the row lives at dword (32 j) ^ sw, i.e. at +sw for even j and -sw for odd j -- two per-lane bases, immediate offsets.
+template <int Q, int LPE> __device__ __forceinline__ void load_row_sw(const float *base, int rl, float (&x)[Geo<Q, LPE>::EPL], int sw)
+{
+    using G = Geo<Q, LPE>;
+    static_assert(G::VW == 4 && LPE == 8 && G::NV % 2 == 0, "swizzled rows: 8 lanes x float4");
+    const float *be = base + rl * 4 + sw, *bo = base + rl * 4 - sw;
+#pragma unroll
+    for (int j = 0; j < G::NV; ++j) {
+        const float4 v = *reinterpret_cast<const float4 *>((j & 1 ? bo : be) + j * 32);
+        x[j * 4 + 0] = v.x; x[j * 4 + 1] = v.y; x[j * 4 + 2] = v.z; x[j * 4 + 3] = v.w;
+    }
+}
+template <int Q, int LPE> __device__ __forceinline__ void store_row_sw(float *base, int rl, const float (&x)[Geo<Q, LPE>::EPL], int sw)
+{
+    using G = Geo<Q, LPE>;
+    static_assert(G::VW == 4 && LPE == 8 && G::NV % 2 == 0, "swizzled rows: 8 lanes x float4");
+    float *be = base + rl * 4 + sw, *bo = base + rl * 4 - sw;
+#pragma unroll
+    for (int j = 0; j < G::NV; ++j)
+        *reinterpret_cast<float4 *>((j & 1 ? bo : be) + j * 32) = float4{x[j * 4 + 0], x[j * 4 + 1], x[j * 4 + 2], x[j * 4 + 3]};
+}
+
 // ------------------------------------------------------------------------------------------------
 // Variable-node top-nm selection (NB_LDPC.c:354-374), one edge per row, literal "nm rounds of first
 // strict minimum below 1e5" semantics.  Writes raw (value, symbol index) pairs to list `t`.
@@ -809,7 +842,7 @@ template <int N> __device__ __forceinline__ unsigned above_mask(const float (&x)
 template <int Q, int LPE, bool RAW = false>
 __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>::EPL], EmsEntry *surv, EmsEntry *inl, int rl,
                                                  int lane, int nm, int lh, const uint8_t *t_i2b, bool rowact, bool &big, float hint, float &T_out,
-                                                 float *drow)
+                                                 float *drow, int sw = 0)   // sw: index swizzle of the staging row (dual_row_swz), else 0
 {
     using G = Geo<Q, LPE>;
     constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
@@ -882,7 +915,8 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     int off = row_excl_scan_i<LPE>(lc, rl);
     if (BYMASK) {
         // park the row in its (now free) staging row so that a lane can fetch the element a mask bit names
-        store_row<Q, LPE>(drow, rl, mvc);
+        if constexpr (LPE == 8 && G::VW == 4 && G::NV % 2 == 0) store_row_sw<Q, LPE>(drow, rl, mvc, sw);
+        else store_row<Q, LPE>(drow, rl, mvc);
         unsigned dbase = (unsigned)(uintptr_t)(lds_f32 *)drow;
         asm volatile("" : "+v"(dbase));
         const lds_f32 *dl = (const lds_f32 *)(uintptr_t)dbase;
@@ -893,7 +927,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                 const int e = __ffs(S) - 1;
                 S &= S - 1u;
                 const unsigned sym = (unsigned)(((e & ~(G::VW - 1)) * LPE) + rl * G::VW + (e & (G::VW - 1)));   // Geo::sym_of
-                svals[off] = dl[sym];
+                svals[off] = dl[sym ^ (unsigned)sw];
                 ssyms[off] = sym;
                 ++off;
             }
@@ -986,7 +1020,7 @@ template <int Q, int LPE, bool DUAL = false>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
                                            EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane,
-                                           bool gact = true
+                                           bool gact
 #ifdef EMS_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long &st_last
 #endif
@@ -1007,6 +1041,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     float *app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
     uint8_t *rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
     float *drow = dense + row * Q;
+    const int sw = DUAL ? dual_row_swz(row) : 0;   // index swizzle of this staging row (see dual_row_swz)
 
     // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279).
     //      Every HBM read of the visit (APP row, record header, the nm record entries) is issued
@@ -1032,10 +1067,11 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
         wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < NREC; ++c)
-            if (rl + c * LPE < cnt) drow[rg[c]] = rv[c];
+            if (rl + c * LPE < cnt) drow[rg[c] ^ sw] = rv[c];
         wave_lds_sync();
         float c[G::EPL];
-        load_row<Q, LPE>(drow, rl, c);
+        if constexpr (DUAL) load_row_sw<Q, LPE>(drow, rl, c, sw);
+        else load_row<Q, LPE>(drow, rl, c);
 #pragma unroll
         for (int e = 0; e < G::EPL; ++e) mvc[e] = mvc[e] - c[e];
     }
@@ -1046,7 +1082,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp) : t * nmp);
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
     float T_sel = __builtin_inff();
-    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow, sw)) {
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
@@ -1091,7 +1127,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     for (int k = rl; k < stp; k += LPE) {
         const EmsEntry e = ol[k];
         const int g = gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1);
-        drow[g] = e.v;
+        drow[g ^ sw] = e.v;
         if (stact) {
             reinterpret_cast<float *>(rec)[k] = e.v;
             rec[EMS_REC_SYM(nm) + k] = (uint8_t)g;
@@ -1104,7 +1140,8 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     }
     wave_lds_sync();
     float napp[G::EPL];
-    load_row<Q, LPE>(drow, rl, napp);
+    if constexpr (DUAL) load_row_sw<Q, LPE>(drow, rl, napp, sw);
+    else load_row<Q, LPE>(drow, rl, napp);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) napp[e] = napp[e] + mvc[e];
     if (stact) store_row<Q, LPE>(app_row, rl, napp);
@@ -1251,7 +1288,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true
 #ifdef EMS_STAMPS
                                , st_acc, st_last
 #endif
@@ -1369,6 +1406,10 @@ __global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
     if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
 
+#ifdef EMS_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
     int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
     unsigned synd = 0;
     for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
@@ -1415,13 +1456,20 @@ __global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
                 default: __builtin_amdgcn_s_setprio(0); break;
                 }
             }
-            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact);
+            STAMP(4);
+            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact
+#ifdef EMS_STAMPS
+                                     , st_acc, st_last
+#endif
+            );
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicOr(&done[cur >> 5], 1u << (cur & 31));
             cur = nxt; cnw = ncnw; vn = nvn; lh = nlh; pred = npred;
         }
+        STAMP(6);
         __syncthreads();
+        STAMP(7);
         if (tid == 0) *next_task = 0;
         for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
         // ---- Syndrom (tools.c:284-299): value of the first check (reference order) with a non-zero sum ----
@@ -1439,11 +1487,16 @@ __global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
         __syncthreads();
         if (tid == 0) *first_bad = 0xFFFFFFFFu;
         synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        STAMP(5);
         if (synd == 0 && P.early_exit) {                       // NB_LDPC.c:470-471
             it = sweep + 1;
             break;
         }
     }
+#ifdef EMS_STAMPS
+    if (lane == 0 && P.stamps)
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], st_acc[i]);
+#endif
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;

@@ -27,6 +27,7 @@ for w in (sys.argv[1:] or ["gf256"]):
     for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
         tot = float(st[grp:grp + 8].sum()) or 1.0
         print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(8)))
+    print("  share of all wave time: " + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[i] + st[8 + i]) / float(st[:16].sum())) for i in range(8)))
     w0 = st[0:8].astype(np.float64); nw = int(os.environ.get("EMS_WAVES", "9")) * B if os.environ.get("EMS_WAVES") else 9 * B
     per_wave_cycles = w0.sum() / nw
     visits = code.M * (itmax - 1) * B
