@@ -244,7 +244,8 @@ void build_pairs(ems_handle *h)
     }
     const int NP = (int)pairs.size();
     h->n_pairs = NP;
-    h->p_cn.assign((size_t)NP * 2, 0); h->p_vn.assign((size_t)NP * 8, 0); h->p_lh.assign((size_t)NP * 8, 0); h->p_pred.assign((size_t)NP * 8, -1);
+    const size_t R = 2 * (size_t)dc;                              // edge rows of a pair
+    h->p_cn.assign((size_t)NP * 2, 0); h->p_vn.assign(NP * R, 0); h->p_lh.assign(NP * R, 0); h->p_pred.assign(NP * R, -1);
     for (int i = 0; i < NP; ++i) {
         const int a = pairs[i].first, b = pairs[i].second;
         const int prio = std::max((h->t_cnp[a] >> 24) & 3, b >= 0 ? (h->t_cnp[b] >> 24) & 3 : 0);
@@ -252,7 +253,7 @@ void build_pairs(ems_handle *h)
             const int t = (m == 1 && b >= 0) ? b : a;          // a single's second half repeats the first, flagged
             h->p_cn[(size_t)i * 2 + m] = (h->t_cnp[t] & 0xFFFFFF) | (prio << 24) | ((m == 1 && b < 0) ? (1 << 30) : 0);
             for (int k = 0; k < dc; ++k) {
-                const size_t src = (size_t)t * dc + k, dst = (size_t)i * 8 + m * 4 + k;
+                const size_t src = (size_t)t * dc + k, dst = (size_t)i * R + (size_t)m * dc + k;
                 h->p_vn[dst] = h->t_vn[src];
                 h->p_lh[dst] = h->t_lh[src];
                 h->p_pred[dst] = h->t_pred[src] < 0 ? -1 : pair_of[h->t_pred[src]];
@@ -552,7 +553,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         }
     }
 
-    if (h->dc == 4) build_pairs(h);
+    if (h->dc == 4 || h->dc == 8) build_pairs(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(EMS_EHIP, "hipEventCreate failed"));
@@ -631,18 +632,27 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     P.occ4 = 0;
     P.dual = 0;
     auto go_dual = [&](int waves) {
-        P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, P.nm);
+        P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
+    };
+    const size_t lds_cap = 160 * 1024;
+    auto dual_fit = [&](int waves) {                          // largest workgroup of the dual kernel within LDS and its launch bound
+        waves = std::min(waves, ems_dual_max_waves(h->dc));
+        while (waves > 1 && ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, waves) > lds_cap) --waves;
+        return waves;
     };
     // developer knobs: EMS_DUAL=<waves per workgroup> forces the two-visits-per-wave kernel, EMS_DUAL=0 forbids it
     const char *ed = getenv("EMS_DUAL");
-    if (allow_dual && ed && atoi(ed) > 0 && ems_has_dual_kernel(P)) { go_dual(std::min(4, atoi(ed))); return; }
+    if (allow_dual && ed && atoi(ed) > 0 && ems_has_dual_kernel(P)) { go_dual(dual_fit(atoi(ed))); return; }
     if (getenv("EMS_WAVES")) { P.occ4 = getenv("EMS_OCC4") ? 1 : 0; return; }
+    // dc = 8 (the GF(16) configuration): the elementary steps are most of a visit, so the dual kernel is used at every
+    // batch size, with the workgroup the one-visit kernel would have had
+    if (allow_dual && !(ed && atoi(ed) == 0) && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }
     if (ems_max_waves_for(h->dc) != 12 || P.waves_per_wg < 12 || h->n_cu <= 0) return;
-    const size_t lds_cap = 160 * 1024, wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
+    const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
     if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 5 && ems_has_dual_kernel(P) &&
-        6 * ((ems_dual_wg_lds_bytes(h->q, P.nm, P.n_pairs, 2) + 1023) & ~(size_t)1023) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 1 KiB units: 27 KiB workgroups ran five to a CU)
+        6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 1023) & ~(size_t)1023) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 1 KiB units: 27 KiB workgroups ran five to a CU)
     if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
     else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }

@@ -11,9 +11,10 @@ int ems_max_waves_for(int dc);                             // waves per workgrou
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 bool ems_has_occ4_kernel(const EmsPlan &P);
-bool ems_has_dual_kernel(const EmsPlan &P);                  // two check-node visits per wave (dc = 4, GF(256), nm = 20)
-size_t ems_dual_wave_lds_bytes(int q, int nm);
-size_t ems_dual_wg_lds_bytes(int q, int nm, int n_pairs, int waves);
+bool ems_has_dual_kernel(const EmsPlan &P);                  // two check-node visits per wave (GF(256) dc 4 nm 20; GF(16) dc 8 nm 8)
+int ems_dual_max_waves(int dc);                              // waves per workgroup k_decode_dual is built for
+size_t ems_dual_wave_lds_bytes(int q, int dc, int nm);
+size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves);
 hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
                               float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st);
 hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st);

@@ -590,24 +590,25 @@ __device__ __forceinline__ uint2 cn_task(int dc, int nmp, int t, int grp)
 // Two visits per wave (k_decode_dual, dc = 4): the wave's list area holds the four input lists of visit 0, the four of
 // visit 1, then the six other lists (prefix, suffix, merges) of visit 0 and of visit 1 -- the selection's survivor
 // scratch aliases everything behind the inputs, which is dead until the elementary steps start.  Offsets in entries.
-constexpr int DUAL_DC = 4, DUAL_NLISTS = DUAL_DC + 3 * (DUAL_DC - 2);
-__host__ __device__ inline int dual_list_off(int half, int id, int nmp)
+// (dc = 4: rows of 8 lanes; dc = 8: rows of 4 lanes.)
+__host__ __device__ constexpr int dual_nlists(int dc) { return dc + 3 * (dc - 2); }
+__host__ __device__ inline int dual_list_off(int half, int id, int nmp, int dc)
 {
-    return id < DUAL_DC ? (half * DUAL_DC + id) * nmp : (2 * DUAL_DC + half * (DUAL_NLISTS - DUAL_DC) + (id - DUAL_DC)) * nmp;
+    return id < dc ? (half * dc + id) * nmp : (2 * dc + half * (dual_nlists(dc) - dc) + (id - dc)) * nmp;
 }
 // task of 8-lane group grp (visit grp >> 2, task grp & 3) in stage t
-__device__ __forceinline__ uint2 cn_task_dual(int nmp, int t, int grp)
+__device__ __forceinline__ uint2 cn_task_dual(int dc, int nmp, int t, int grp)
 {
-    const int half = grp >> 2, dc = DUAL_DC;
+    const int half = grp >> 2;
     const uint2 tk = cn_task(dc, 1, t, grp & 3);                 // nmp = 1: offsets / 8 = list ids
     if ((tk.y >> 16) == 0u) return uint2{0u, 0u};
     const int a = (int)(tk.x & 0xFFFFu) / 8, b = (int)(tk.x >> 16) / 8, o = (int)(tk.y & 0xFFFFu) / 8;
-    return uint2{(unsigned)(dual_list_off(half, a, nmp) * 8) | ((unsigned)(dual_list_off(half, b, nmp) * 8) << 16),
-                 (unsigned)(dual_list_off(half, o, nmp) * 8) | ((unsigned)(half * DUAL_NLISTS + o + 1) << 16)};
+    return uint2{(unsigned)(dual_list_off(half, a, nmp, dc) * 8) | ((unsigned)(dual_list_off(half, b, nmp, dc) * 8) << 16),
+                 (unsigned)(dual_list_off(half, o, nmp, dc) * 8) | ((unsigned)(half * dual_nlists(dc) + o + 1) << 16)};
 }
-__device__ __forceinline__ void cn_sched_build_dual(uint2 *sched, int nm, int tid, int nthreads)
+__device__ __forceinline__ void cn_sched_build_dual(uint2 *sched, int dc, int nm, int tid, int nthreads)
 {
-    for (int i = tid; i < (DUAL_DC - 2) * 8; i += nthreads) sched[i] = cn_task_dual(list_stride(nm), (i >> 3) + 1, i & 7);
+    for (int i = tid; i < (dc - 2) * 8; i += nthreads) sched[i] = cn_task_dual(dc, list_stride(nm), (i >> 3) + 1, i & 7);
 }
 
 // filled once per kernel by the whole workgroup (caller synchronises)
@@ -1027,13 +1028,15 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
                                            )
 {
     using G = Geo<Q, LPE>;
-    static_assert(!DUAL || LPE == 8, "two visits per wave: 8 rows of 8 lanes");
+    static_assert(!DUAL || LPE == 8 || LPE == 4, "two visits per wave: 2 x 4 rows of 8 lanes or 2 x 8 rows of 4");
+    constexpr int DCD = 32 / LPE;                  // check degree of the two-visit layout
+    constexpr bool SWZ = DUAL && LPE == 8 && G::VW == 4 && G::NV % 2 == 0;   // swizzled staging rows (dual_row_swz)
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
-    const int half = DUAL ? row >> 2 : 0;
+    const int half = DUAL ? row / DCD : 0;
     const bool rowact = DUAL ? true : row < C.dc;  // the row computes (LDS side)
     const bool stact = DUAL ? gact : rowact;       // ... and stores its results to HBM
-    const int t = DUAL ? (row & 3) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
+    const int t = DUAL ? (row % DCD) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
     const int nm = C.nm;
     const int qm1 = Q - 1;
     const int edge = cn * C.dc + t;
@@ -1041,7 +1044,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     float *app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
     uint8_t *rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
     float *drow = dense + row * Q;
-    const int sw = DUAL ? dual_row_swz(row) : 0;   // index swizzle of this staging row (see dual_row_swz)
+    const int sw = SWZ ? dual_row_swz(row) : 0;   // index swizzle of this staging row (see dual_row_swz)
 
     // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279).
     //      Every HBM read of the visit (APP row, record header, the nm record entries) is issued
@@ -1070,7 +1073,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
             if (rl + c * LPE < cnt) drow[rg[c] ^ sw] = rv[c];
         wave_lds_sync();
         float c[G::EPL];
-        if constexpr (DUAL) load_row_sw<Q, LPE>(drow, rl, c, sw);
+        if constexpr (SWZ) load_row_sw<Q, LPE>(drow, rl, c, sw);
         else load_row<Q, LPE>(drow, rl, c);
 #pragma unroll
         for (int e = 0; e < G::EPL; ++e) mvc[e] = mvc[e] - c[e];
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(0);
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
     const int nmp = list_stride(nm);
-    EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp) : t * nmp);
+    EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp, DCD) : t * nmp);
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
     float T_sel = __builtin_inff();
     if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow, sw)) {
@@ -1119,8 +1122,8 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
-    const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp) : oid * nmp);
-    const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * DUAL_NLISTS + oid : oid];
+    const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp, DCD) : oid * nmp);
+    const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * dual_nlists(DCD) + oid : oid];
     const float dflt = ol[stp - 1].v + C.offset;
     fill_row<Q, LPE>(drow, rl, dflt);
     wave_lds_sync();
@@ -1140,7 +1143,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     }
     wave_lds_sync();
     float napp[G::EPL];
-    if constexpr (DUAL) load_row_sw<Q, LPE>(drow, rl, napp, sw);
+    if constexpr (SWZ) load_row_sw<Q, LPE>(drow, rl, napp, sw);
     else load_row<Q, LPE>(drow, rl, napp);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) napp[e] = napp[e] + mvc[e];
@@ -1347,20 +1350,24 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
 // LDS carve: [idx2bin Q][bin2idx Q][first_bad, next_task, spin_fail, pad][schedule 2 x 8 tasks][done bits] then per
 // wave: 8 staging rows | 8 input lists | 12 other lists | lens | picks  (survivors alias from the other lists on).
 // ------------------------------------------------------------------------------------------------
-constexpr int DUAL_SCHED_BYTES = (DUAL_DC - 2) * 8 * 8;
-__host__ __device__ inline int dual_header_bytes(int q, int n_pairs) { return 2 * q + 16 + DUAL_SCHED_BYTES + (((n_pairs + 31) / 32 * 4 + 15) & ~15); }
-__host__ __device__ inline int dual_wave_bytes(int q, int nm)
+__host__ __device__ constexpr int dual_sched_bytes(int dc) { return (dc - 2) * 8 * 8; }
+__host__ __device__ inline int dual_header_bytes(int q, int dc, int n_pairs) { return 2 * q + 16 + dual_sched_bytes(dc) + (((n_pairs + 31) / 32 * 4 + 15) & ~15); }
+__host__ __device__ inline int dual_dense_bytes(int q, int dc) { return (2 * dc * q > 8 * q ? 2 * dc * q : 8 * q) * 4; }   // 2 dc staging rows; at least the 8 dedupe tables
+__host__ __device__ inline int dual_wave_bytes(int q, int dc, int nm)
 {
-    const int nmp = list_stride(nm);
-    const int other = (2 * (DUAL_NLISTS - DUAL_DC) * nmp * 8 + 2 * DUAL_NLISTS * 4 + ES_PICK_BYTES + 15) & ~15;   // other lists | lens | picks
-    const int survb = 8 * surv_stride(8) * 8;
-    return 8 * q * 4 + 2 * DUAL_DC * nmp * 8 + (other > survb ? other : ((survb + 15) & ~15));
+    const int nmp = list_stride(nm), nl = dual_nlists(dc), lpe = 32 / dc;
+    const int other = (2 * (nl - dc) * nmp * 8 + ((2 * nl * 4 + 15) & ~15) + ES_PICK_BYTES + 15) & ~15;   // other lists | lens | picks
+    const int survb = 2 * dc * surv_stride(lpe) * 8;
+    return dual_dense_bytes(q, dc) + 2 * dc * nmp * 8 + (other > survb ? other : ((survb + 15) & ~15));
 }
 
-template <int Q, int NM>
-__global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
+// DC = 4 (GF(256) headline): at most four waves per workgroup, 168 VGPRs for three waves per SIMD.
+// DC = 8 (GF(16), 4 symbols per lane): up to 16 waves per workgroup.
+template <int Q, int NM, int DC>
+__global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decode_dual(const EmsPlan P)
 {
-    constexpr int LPE = 8;
+    constexpr int LPE = 32 / DC;
+    constexpr int DUAL_DC = DC, DUAL_NLISTS = dual_nlists(DC), DUAL_SCHED_BYTES = dual_sched_bytes(DC);
     Cfg C;
     C.dc = DUAL_DC;
     C.nm = NM > 0 ? NM : P.nm;
@@ -1385,24 +1392,24 @@ __global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
     const int f = blockIdx.x;
     const int rl = lane & (LPE - 1);
     const int row = lane / LPE;
-    const int half = row >> 2;
-    const int oid = P.out_list[row & 3];
+    const int half = row / DC;
+    const int oid = P.out_list[row % DC];
 
     const int nmp = list_stride(C.nm);
-    uint8_t *wbase = smem + dual_header_bytes(Q, NP) + (size_t)wave * P.wave_lds_bytes;
+    uint8_t *wbase = smem + dual_header_bytes(Q, DC, NP) + (size_t)wave * P.wave_lds_bytes;
     float *dense = reinterpret_cast<float *>(wbase);
-    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + 8 * Q * 4);
-    uint8_t *other = wbase + 8 * Q * 4 + 2 * DUAL_DC * nmp * 8;
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + dual_dense_bytes(Q, DC));
+    uint8_t *other = wbase + dual_dense_bytes(Q, DC) + 2 * DUAL_DC * nmp * 8;
     EmsEntry *surv = reinterpret_cast<EmsEntry *>(other);                       // dead before the elementary steps start
     int *lens = reinterpret_cast<int *>(other + 2 * (DUAL_NLISTS - DUAL_DC) * nmp * 8);
-    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + 2 * DUAL_NLISTS * 4;
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((2 * DUAL_NLISTS * 4 + 15) & ~15);
 
     for (int i = tid; i < Q; i += blockDim.x) {
         t_i2b[i] = P.idx2bin[i];
         t_b2i[i] = P.bin2idx[i];
     }
     for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
-    cn_sched_build_dual(sched, C.nm, tid, blockDim.x);
+    cn_sched_build_dual(sched, DC, C.nm, tid, blockDim.x);
     if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
     __syncthreads();
 
@@ -1422,18 +1429,18 @@ __global__ void __launch_bounds__(256, 3) k_decode_dual(const EmsPlan P)
         int cnw = 0, vn = 0, lh = 0, pred = -1;
         if (cur < NP) {
             cnw = P.p_cn[cur * 2 + half];                      // check node | priority << 24 | (no visit of its own) << 30
-            vn = P.p_vn[cur * 8 + row];
-            lh = P.p_lh[cur * 8 + row];
-            pred = P.p_pred[cur * 8 + row];
+            vn = P.p_vn[cur * (2 * DC) + row];
+            lh = P.p_lh[cur * (2 * DC) + row];
+            pred = P.p_pred[cur * (2 * DC) + row];
         }
         while (cur < NP) {                                     // NB_LDPC.c:320, in dependency order
             const int nxt = claim();                           // the following pair's descriptor travels under this one
             int ncnw = 0, nvn = 0, nlh = 0, npred = -1;
             if (nxt < NP) {
                 ncnw = P.p_cn[nxt * 2 + half];
-                nvn = P.p_vn[nxt * 8 + row];
-                nlh = P.p_lh[nxt * 8 + row];
-                npred = P.p_pred[nxt * 8 + row];
+                nvn = P.p_vn[nxt * (2 * DC) + row];
+                nlh = P.p_lh[nxt * (2 * DC) + row];
+                npred = P.p_pred[nxt * (2 * DC) + row];
             }
             const bool gact = ((cnw >> 30) & 1) == 0;
             {   // wait for the previous visitors of my variable nodes (same sweep)
@@ -2275,15 +2282,19 @@ template <int Q, int LPE, int DC = 0, int NM = 0, bool OCC4 = false> static hipE
 }
 static bool spec_ok(const EmsPlan &P) { return P.nbOper >= P.nm + 3 && P.nbOper <= 64; }
 // two-visits-per-wave build (k_decode_dual): the BASELINE headline configuration
-bool ems_has_dual_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == DUAL_DC && P.nm == 20 && P.n_pairs > 0; }
-size_t ems_dual_wave_lds_bytes(int q, int nm) { return (size_t)dual_wave_bytes(q, nm); }
-size_t ems_dual_wg_lds_bytes(int q, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, n_pairs) + (size_t)dual_wave_bytes(q, nm) * waves; }
-template <int Q, int NM> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
+bool ems_has_dual_kernel(const EmsPlan &P)
 {
-    const size_t lds = ems_dual_wg_lds_bytes(Q, P.nm, P.n_pairs, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode_dual<Q, NM>, lds);
+    return spec_ok(P) && P.n_pairs > 0 && ((P.q == 256 && P.dc == 4 && P.nm == 20) || (P.q == 16 && P.dc == 8 && P.nm == 8));
+}
+int ems_dual_max_waves(int dc) { return dc == 4 ? 4 : 16; }
+size_t ems_dual_wave_lds_bytes(int q, int dc, int nm) { return (size_t)dual_wave_bytes(q, dc, nm); }
+size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, dc, n_pairs) + (size_t)dual_wave_bytes(q, dc, nm) * waves; }
+template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    const size_t lds = ems_dual_wg_lds_bytes(Q, DC, P.nm, P.n_pairs, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_dual<Q, NM, DC>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_decode_dual<Q, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipLaunchKernelGGL((k_decode_dual<Q, NM, DC>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
 // kernels that also exist in the 16-waves-per-CU build
@@ -2295,8 +2306,10 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
     const bool spec = spec_ok(P);
     if (P.dual) {
-        if (!ems_has_dual_kernel(P) || P.waves_per_wg > 4 || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.nm)) return hipErrorInvalidValue;
-        return launch_decode_dual_t<256, 20>(P, B, st);
+        if (!ems_has_dual_kernel(P) || P.waves_per_wg > ems_dual_max_waves(P.dc) || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.dc, P.nm))
+            return hipErrorInvalidValue;
+        if (P.dc == 4) return launch_decode_dual_t<256, 20, 4>(P, B, st);
+        return launch_decode_dual_t<16, 8, 8>(P, B, st);
     }
     if (P.occ4 && P.waves_per_wg <= 4 && ems_has_occ4_kernel(P)) return launch_decode_t<256, 16, 4, 20, true>(P, B, st);
     if (spec && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);

@@ -48,13 +48,13 @@ struct EmsPlan {
     const int *t_vn;        // [M*dc] its variable nodes
     const int *t_lh;        // [M*dc] log of its coefficients
     const int *t_pred;      // [M*dc] task index of the previous visitor of that variable node in this sweep, or -1
-    // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4): the members of a pair
+    // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)
-    const int *p_vn;        // [n_pairs*8] variable nodes, row = member * 4 + edge
-    const int *p_lh;        // [n_pairs*8] log of the coefficients
-    const int *p_pred;      // [n_pairs*8] PAIR index of the previous visitor of that variable node in this sweep, or -1
+    const int *p_vn;        // [n_pairs*2dc] variable nodes, row = member * dc + edge
+    const int *p_lh;        // [n_pairs*2dc] log of the coefficients
+    const int *p_pred;      // [n_pairs*2dc] PAIR index of the previous visitor of that variable node in this sweep, or -1
     int nsteps;             // dc-2 forward/backward steps
     int8_t out_list[16];    // list id holding the output for edge t
     int n_lists;

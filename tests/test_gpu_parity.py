@@ -207,6 +207,20 @@ def test_decode_gf16_vs_oracle(pkg, orc):
     assert list(it) == [6, 5, 5, 5]                    # K3
 
 
+def test_decode_gf16_one_visit_per_wave_kernel_vs_oracle(pkg, orc, monkeypatch):
+    """dc = 8 codes take the two-visits-per-wave kernel by default; EMS_DUAL=0 keeps the one-visit kernel reachable."""
+    monkeypatch.setenv("EMS_DUAL", "0")
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 4, state=True)
+    assert list(it) == [6, 5, 5, 5]
+
+
+def test_decode_gf16_state_and_fixed_work(pkg, orc):
+    """The GF(16) configuration on its default (two-visits-per-wave) kernel: full APP / C->V state, and a
+    non-converging fixed-work run."""
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 2, state=True)
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 6, 0.0, 2, state=True, early_exit=False)
+
+
 def test_decode_gf256_vs_oracle(pkg, orc):
     it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.6, 4)
     assert list(it) == [30, 30, 30, 25]                # K4: frame 4 converges in 25 sweeps
