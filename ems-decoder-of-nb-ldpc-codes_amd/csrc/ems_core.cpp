@@ -652,7 +652,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
     if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 5 && ems_has_dual_kernel(P) &&
-        6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 1023) & ~(size_t)1023) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 1 KiB units: 27 KiB workgroups ran five to a CU)
+        6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 2 KiB units: 27 KiB workgroups ran five to a CU, 13 KiB ones eleven)
     if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
     else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }

@@ -415,12 +415,29 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
         li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
         sy &= 0xFFu;
     };
+    {   // the NJ picks of this lane, phase by phase so that each phase is ONE LDS round trip: pick bytes, then the
+        // two source entries of every pick, then the arithmetic (same operations as gather() above)
+        unsigned pkb[NJ];
+        EmsEntry e1[NJ], e2[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int i = p + TL * j;
-        int li;
-        gather(i, has && i < T, val[j], sym[j], li);
-        lim = min(lim, li);
+        for (int j = 0; j < NJ; ++j) pkb[j] = picks[(has && p + TL * j < T) ? p + TL * j : 0];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int w = pkb[j] >> 5, k = pkb[j] & 31;
+            constexpr int NFIX = FL ? 2 : 4;
+            e1[j] = in1[w < NFIX ? w : k];
+            e2[j] = in2[w < NFIX ? k : w - NFIX];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = p + TL * j, k = pkb[j] & 31;
+            const bool ok = has && i < T;
+            val[j] = e1[j].v + e2[j].v;
+            const unsigned sy = sym_comb(e1[j].s, e2[j].s);
+            const int li = !ok ? (1 << 20) : ((sy & EMS_S_INVALID) ? i : (k >= nm - 1 ? i + 1 : (1 << 20)));
+            sym[j] = sy & 0xFFu;
+            lim = min(lim, li);
+        }
     }
     lim = redT_mini<TL>(lim);
     bool stopped = lim <= T;
@@ -433,10 +450,13 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
     }
     wave_lds_sync();
     int base = 0;
+    unsigned tv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tv[j] = tbl[sym[j]];          // (all read-backs in flight together: one round trip)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int i = p + TL * j;
-        const bool u = has && i < lim && tbl[sym[j]] == (unsigned)(ES_MAX_STEPS - i);
+        const bool u = has && i < lim && tv[j] == (unsigned)(ES_MAX_STEPS - i);
         const unsigned m8 = (unsigned)(__ballot(u) >> gbase) & ((1u << TL) - 1u);
         const int sidx = base + __popc(m8 & ((1u << p) - 1u));
         if (u && sidx < nm) out[sidx] = EmsEntry{val[j], sym[j]};
@@ -923,14 +943,27 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         const lds_f32 *dl = (const lds_f32 *)(uintptr_t)dbase;
         unsigned S = ~am & (G::EPL >= 32 ? 0xFFFFFFFFu : ((1u << (G::EPL & 31)) - 1u));
         wave_lds_sync();
+        // four survivors per round: their values are requested together (one LDS round trip per round instead of one per
+        // survivor); a lane that has run out reads element 0 and parks it in its dummy slot
         while (__ballot(S != 0u) != 0ull) {
-            if (S != 0u) {
-                const int e = __ffs(S) - 1;
+            constexpr int R = 4;
+            unsigned symk[R];
+            float vk[R];
+            bool hk[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                hk[k] = S != 0u;
+                const int e = hk[k] ? __ffs(S) - 1 : 0;
                 S &= S - 1u;
-                const unsigned sym = (unsigned)(((e & ~(G::VW - 1)) * LPE) + rl * G::VW + (e & (G::VW - 1)));   // Geo::sym_of
-                svals[off] = dl[sym ^ (unsigned)sw];
-                ssyms[off] = sym;
-                ++off;
+                symk[k] = (unsigned)(((e & ~(G::VW - 1)) * LPE) + rl * G::VW + (e & (G::VW - 1)));   // Geo::sym_of
+                vk[k] = dl[symk[k] ^ (unsigned)sw];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int slot = hk[k] ? off : SEL_CAP + rl;
+                svals[slot] = vk[k];
+                ssyms[slot] = symk[k];
+                off += hk[k] ? 1 : 0;
             }
         }
     } else {
