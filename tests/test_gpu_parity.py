@@ -443,6 +443,15 @@ def test_full_size_headline_batch1024_shapes_agree(pkg, orc):
     big.close(); small.close()
 
 
+def test_decode_n96_two_visits_per_wave_vs_oracle(pkg, orc, monkeypatch):
+    """The GF(64) build of k_decode_dual (picked for the N96 code from 4 frames per CU on), forced on a small batch:
+    one-wave and two-wave workgroups, full state."""
+    for waves in ("1", "2"):
+        monkeypatch.setenv("EMS_DUAL", waves)
+        _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 10, 2.0, 48, state=True)
+        _decode_vs_oracle(pkg, orc, "KN_N96_K48_GF64.txt", 16, 32, 0.3, 30, -3.0, 8, state=True, early_exit=False)
+
+
 def test_full_size_n96_batch8192(pkg, orc):
     path = os.path.join(MAT, "N96_K48_GF64")
     o = orc.Oracle(path)
