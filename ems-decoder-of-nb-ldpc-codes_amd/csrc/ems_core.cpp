@@ -243,6 +243,65 @@ void build_pairs(ems_handle *h)
         pairs.emplace_back(a, b);
     }
     const int NP = (int)pairs.size();
+    // Claim order of the pairs.  The kernel hands pair i to whichever wave of the frame's workgroup asks next, and a wave
+    // whose pair has an unpublished predecessor waits -- level by level that happens at every level boundary (the first
+    // pair of a level depends on the last pairs of the level before, still running on the other wave).  So the list is
+    // re-ordered by a list-scheduling run on two waves with unit visit times: at every claim the ready pair (all
+    // predecessors finished by then) that heads the longest remaining chain goes first; when none is ready, the one whose
+    // predecessors finish soonest.  Any topological order gives the same bits; this one keeps the waves from waiting.
+    if (!getenv("EMS_PAIR_ORDER") || atoi(getenv("EMS_PAIR_ORDER")) != 0) {
+        std::vector<std::vector<int>> pp(NP), succ(NP);
+        for (int i = 0; i < NP; ++i)
+            for (int t : {pairs[i].first, pairs[i].second}) {
+                if (t < 0) continue;
+                for (int k = 0; k < dc; ++k) {
+                    const int pr = h->t_pred[(size_t)t * dc + k];
+                    if (pr >= 0 && pair_of[pr] != i) pp[i].push_back(pair_of[pr]);
+                }
+            }
+        for (int i = 0; i < NP; ++i) {
+            std::sort(pp[i].begin(), pp[i].end());
+            pp[i].erase(std::unique(pp[i].begin(), pp[i].end()), pp[i].end());
+            for (int q : pp[i]) succ[q].push_back(i);
+        }
+        std::vector<int> height(NP, 0), npend(NP), order;
+        for (int i = NP - 1; i >= 0; --i)
+            for (int q : pp[i]) height[q] = std::max(height[q], height[i] + 1);   // (pairs are in a topological order)
+        std::vector<double> fin(NP, -1.0), ready_at(NP, 0.0);
+        for (int i = 0; i < NP; ++i) npend[i] = (int)pp[i].size();
+        std::vector<int> avail;                                 // predecessors all placed
+        for (int i = 0; i < NP; ++i)
+            if (!npend[i]) avail.push_back(i);
+        const int W = 2;
+        double free_at[W] = {0.0, 0.0};
+        order.reserve(NP);
+        while ((int)order.size() < NP) {
+            const int w = free_at[0] <= free_at[1] ? 0 : 1;
+            const double now = free_at[w];
+            int best = -1;
+            for (int c : avail)                                 // ready now: longest chain first (then list order)
+                if (ready_at[c] <= now && (best < 0 || height[c] > height[best] || (height[c] == height[best] && c < best))) best = c;
+            if (best < 0)
+                for (int c : avail)                             // nothing ready: the soonest
+                    if (best < 0 || ready_at[c] < ready_at[best] || (ready_at[c] == ready_at[best] && height[c] > height[best])) best = c;
+            avail.erase(std::find(avail.begin(), avail.end(), best));
+            const double start = std::max(now, ready_at[best]);
+            fin[best] = start + 1.0;
+            free_at[w] = fin[best];
+            order.push_back(best);
+            for (int sc : succ[best]) {
+                ready_at[sc] = std::max(ready_at[sc], fin[best]);
+                if (--npend[sc] == 0) avail.push_back(sc);
+            }
+        }
+        std::vector<std::pair<int, int>> np2(NP);
+        for (int i = 0; i < NP; ++i) np2[i] = pairs[order[i]];
+        pairs.swap(np2);
+        for (int i = 0; i < NP; ++i) {
+            pair_of[pairs[i].first] = i;
+            if (pairs[i].second >= 0) pair_of[pairs[i].second] = i;
+        }
+    }
     h->n_pairs = NP;
     const size_t R = 2 * (size_t)dc;                              // edge rows of a pair
     h->p_cn.assign((size_t)NP * 2, 0); h->p_vn.assign(NP * R, 0); h->p_lh.assign(NP * R, 0); h->p_pred.assign(NP * R, -1);
