@@ -18,6 +18,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("EMS_LIB") or os.path.join(PKG_DIR, "libems_hip.so")  # EMS_LIB: developer override (ablation builds)
 SIM_PATH = os.path.join(PKG_DIR, "ems_sim")
 
+LLR_SUM, LLR_SSD = 0, 1   # ems_abi.h: EMS_LLR_SUM / EMS_LLR_SSD
 EMS_OK, EMS_EINVAL, EMS_ENODEV, EMS_EHIP, EMS_EIO, EMS_ENOMEM, EMS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -72,6 +73,7 @@ def lib():
         L.ems_llr_init.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.ems_llr_init_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.ems_load_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ems_llr_init_constellation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
         L.ems_decode.argtypes = [C.c_void_p, C.c_int]
         L.ems_get_results.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ems_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -177,6 +179,19 @@ class Decoder:
         B = noisy.shape[0]
         assert noisy.shape == (B, self.code.N, self.code.logGF)
         _check(lib().ems_llr_init(self.h, _ptr(noisy), np.float32(sigma), B))
+        return B
+
+    def llr_init_constellation(self, obs, att, table, mode, sigma):
+        """Constellation front ends (channel.c:112-929): obs / att [B][N][D], table [GF][D] by binary image,
+        mode LLR_SUM (att may be None) or LLR_SSD."""
+        obs = np.ascontiguousarray(obs, np.float32)
+        B, N, D = obs.shape
+        assert N == self.code.N
+        att = None if att is None else np.ascontiguousarray(att, np.float32)
+        table = np.ascontiguousarray(table, np.float32)
+        assert table.shape == (self.code.GF, D) and (att is None or att.shape == obs.shape)
+        _check(lib().ems_llr_init_constellation(self.h, _ptr(obs), _ptr(att) if att is not None else None, _ptr(table), D, mode,
+                                                np.float32(sigma), B))
         return B
 
     def llr_init_dev(self, dev_ptr, sigma, B):

@@ -188,7 +188,7 @@ struct ems_handle {
     DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp, d_iso_vn, d_p_cn, d_p_vn, d_p_lh, d_p_pred;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
     DevBuf<int8_t> d_sched;
-    DevBuf<float> d_app, d_noisy, d_scratch;
+    DevBuf<float> d_app, d_noisy, d_scratch, d_att, d_ctable;   // d_att / d_ctable: constellation front ends (allocated on first use)
     DevBuf<unsigned long long> d_stamps;
     // v2 flavour (allocated on first ems_v2_load_likelihood)
     std::vector<int> v2_t_dst, v2_vn_edge;
@@ -510,7 +510,7 @@ void ems_destroy(ems_handle *h)
     for (DevBuf<uint8_t> *b : {&h->d_src_tcoef, &h->d_src_rcoef, &h->d_src_diag, &h->d_src_sym, &h->d_src_rhs}) b->release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
-    h->d_scratch.release(); h->d_stamps.release();
+    h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
@@ -668,6 +668,38 @@ int ems_llr_init(ems_handle *h, const float *noisy_host, float sigma, int B)
     if (!noisy_host) return fail(EMS_EINVAL, "null noisy pointer");
     HIP_TRY(hipMemcpyAsync(h->d_noisy.p, noisy_host, (size_t)B * h->N * h->logq * sizeof(float), hipMemcpyHostToDevice, h->stream));
     return ems_llr_init_dev(h, h->d_noisy.p, sigma, B);
+}
+
+// ---- constellation channel front ends (kernel k_llr_const) ----
+int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, int D, int mode,
+                               float sigma, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!obs_host || !table_host) return fail(EMS_EINVAL, "null observation or table pointer");
+    if (D != 2 && D != 4) return fail(EMS_EINVAL, "constellation dimension %d: 2 or 4", D);
+    if (mode != EMS_LLR_SUM && mode != EMS_LLR_SSD) return fail(EMS_EINVAL, "unknown LLR mode %d", mode);
+    if (mode == EMS_LLR_SUM && D != 2) return fail(EMS_EINVAL, "EMS_LLR_SUM is the two-dimensional form (channel.c:277)");
+    if (mode == EMS_LLR_SSD && !att_host) return fail(EMS_EINVAL, "EMS_LLR_SSD needs the per-axis attenuations");
+    if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "constellation front ends: GF(64) and GF(256) (the reference's, channel.c:344 / :395)");
+    if (!(sigma > 0.f)) return fail(EMS_EINVAL, "sigma must be > 0");
+    if (D > h->logq) return fail(EMS_EINVAL, "D exceeds the staging buffer");
+    const size_t n = (size_t)B * h->N * D;
+    if (!h->d_ctable.p && (r = h->d_ctable.alloc(256 * 4))) return r;
+    if (mode == EMS_LLR_SSD && h->d_att.n < (size_t)h->max_batch * h->N * 4) {
+        h->d_att.release();
+        if ((r = h->d_att.alloc((size_t)h->max_batch * h->N * 4))) return r;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_noisy.p, obs_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));   // ([B][N][logGF] staging holds [B][N][D])
+    if (mode == EMS_LLR_SSD) HIP_TRY(hipMemcpyAsync(h->d_att.p, att_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_ctable.p, table_host, (size_t)h->q * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(ems_launch_llr_const(h->d_noisy.p, mode == EMS_LLR_SSD ? h->d_att.p : nullptr, h->d_ctable.p, h->q, D, mode, sigma, (size_t)B * h->N,
+                                 h->d_b2i.p, h->d_app.p, h->stream));
+    if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_llr_ev = true;
+    return EMS_OK;
 }
 
 int ems_load_llr(ems_handle *h, const float *llr_host, int B)

@@ -22,6 +22,8 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st);
 hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
                                const uint8_t *idx2bin_dev, const uint8_t *bin2idx_dev, float *app_dev, hipStream_t st);
+hipError_t ems_launch_llr_const(const float *obs_dev, const float *att_dev, const float *table_dev, int q, int D, int mode, float sigma,
+                                size_t nvn, const uint8_t *bin2idx_dev, float *app_dev, hipStream_t st);
 hipError_t ems_launch_count_errors(const uint8_t *decide_dev, const int *cw_dev, int B, int N, int K,
                                    const uint8_t *idx2bin_dev, int *nberr_dev, hipStream_t st);
 hipError_t ems_launch_expand_ctov(const uint8_t *rec_dev, int rec_bytes, int nm, int q, int E, float *out_dev,

@@ -30,6 +30,9 @@ namespace {
 // accumulated per wave and added to P.stamps at kernel end.  Never compiled into the product.
 #ifdef EMS_STAMPS
 #define STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#define ST_PARAMS , unsigned long long (&st_acc)[16], unsigned long long &st_last
+#define ST_ARGS , st_acc, st_last
+#define ST_DUMMY unsigned long long st_acc[16] = {}; unsigned long long st_last = 0; (void)st_acc; (void)st_last;
 __device__ unsigned long long g_dbg[8];
 #ifdef EMS_COUNTERS
 #define DBG_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[i], (unsigned long long)(v)); } while (0)
@@ -39,6 +42,9 @@ __device__ unsigned long long g_dbg[8];
 #else
 #define STAMP(i) do { } while (0)
 #define DBG_ADD(i, v) do { } while (0)
+#define ST_PARAMS
+#define ST_ARGS
+#define ST_DUMMY
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -503,7 +509,7 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
 
 template <int TL = 16>
 __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
-                                              int lane, uint2 task, int nm, int nbOper, int T1)
+                                              int lane, uint2 task, int nm, int nbOper, int T1 ST_PARAMS)
 {
     // A task owns TL lanes.  The merge needs 8 (its 8 competitors): with TL = 16 both halves run it identically (same
     // inputs, same picks written to the same bytes); the post-pass then spreads the picks over all TL lanes.
@@ -543,13 +549,16 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     int S = 0;
     bool done;
     init();
+    STAMP(8);
     es_merge<false>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
+    STAMP(9);
     DBG_ADD(3, 1);
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
         DBG_ADD(5, 1);
         init();
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
+    STAMP(10);
     int Td = T1;   // picks merged so far
     if (T1 <= TL) done = es_post<1, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
     else if (T1 <= 2 * TL) done = es_post<2, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
@@ -562,6 +571,7 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
         es_post_rt<0, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
     }
+    STAMP(11);
     if (has && p16 == 0) lens[o_id] = S;
 }
 
@@ -640,13 +650,13 @@ __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int
 // TL lanes per elementary-step task: 16 (one visit per wave; the literal form uses 8 of them twice over) or 8 (two visits)
 template <int TL = 16>
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
-                                        int lane, bool literal)
+                                        int lane, bool literal ST_PARAMS)
 {
     const int grp = lane / TL;
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= C.nsteps; ++t) {
         const uint2 task = sched[(t - 1) * 8 + grp];
-        if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1);
+        if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else {
             // literal form: list ids from the byte offsets (es_stage takes entry pointers through ids of stride nmp)
             const int lb = list_stride(C.nm) * 8;
@@ -1054,11 +1064,7 @@ template <int Q, int LPE, bool DUAL = false>
 __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
                                            EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane,
-                                           bool gact
-#ifdef EMS_STAMPS
-                                           , unsigned long long (&st_acc)[8], unsigned long long &st_last
-#endif
-                                           )
+                                           bool gact ST_PARAMS)
 {
     using G = Geo<Q, LPE>;
     static_assert(!DUAL || LPE == 8 || LPE == 4, "two visits per wave: 2 x 4 rows of 8 lanes or 2 x 8 rows of 4");
@@ -1150,7 +1156,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     unsigned *tbl = reinterpret_cast<unsigned *>(dense);
     for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
     wave_lds_sync();
-    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
+    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull ST_ARGS);
 
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
@@ -1265,7 +1271,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
     __syncthreads();
 
 #ifdef EMS_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_readcyclecounter();
 #endif
     int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
@@ -1324,11 +1330,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true
-#ifdef EMS_STAMPS
-                               , st_acc, st_last
-#endif
-            );
+            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true ST_ARGS);
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1447,7 +1449,7 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decod
     __syncthreads();
 
 #ifdef EMS_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_readcyclecounter();
 #endif
     int it = P.nsweeps + 1; // value added to sum_it when the frame never converges (NB_LDPC.c:474)
@@ -1497,11 +1499,7 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decod
                 }
             }
             STAMP(4);
-            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact
-#ifdef EMS_STAMPS
-                                     , st_acc, st_last
-#endif
-            );
+            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicOr(&done[cur >> 5], 1u << (cur & 31));
@@ -1535,7 +1533,7 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decod
     }
 #ifdef EMS_STAMPS
     if (lane == 0 && P.stamps)
-        for (int i = 0; i < 8; ++i) atomicAdd(&P.stamps[i], st_acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&P.stamps[i], st_acc[i]);
 #endif
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
@@ -2089,6 +2087,64 @@ __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ nois
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Channel LLR of the constellation front ends (channel.c:270-283 ModelChannel_AWGN_64, :676-704 ModelChannel,
+// :861-888 ModelChannel_AWGN_256QAM_4D): one GF(q) symbol = one point of a D-dimensional
+// constellation (D = 2 or 4), observed per axis with an attenuation (fading, 0 = erased axis).
+//   mode 0 (SUM): TMP = SQR(y0 - t0)/(2.0*SQR(sigma)) + SQR(y1 - t1)/(2.0*SQR(sigma))   -- both quotients double, one rounding
+//   mode 1 (SSD): TMP = 0; per axis with attenuation > 0: TMP = TMP + SQR(y - a*t)/(2.0*SQR(sigma))   -- float running value
+// with the reference's promotions: differences, products and squares in float, quotient and sum in double.
+// One wavefront per (frame, variable node): the table [q][D] (indexed by the symbol's BINARY IMAGE, as the reference's
+// `som`) sits in LDS, lane i evaluates the images i + 64 h, the results pass through a per-wave LDS row (image -> symbol
+// index) and leave as one coalesced store.  q = 64 or 256.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs, const float *__restrict__ att,
+                                                   const float *__restrict__ table, int q, int D, int mode, float sigma, size_t nvn,
+                                                   const uint8_t *__restrict__ bin2idx, float *__restrict__ app)
+{
+    __shared__ float tab[256 * 4];
+    __shared__ uint8_t b2i[256];
+    __shared__ __attribute__((aligned(16))) float row[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < q * D; i += blockDim.x) tab[i] = table[i];
+    for (int i = threadIdx.x; i < q; i += blockDim.x) b2i[i] = bin2idx[i];
+    __syncthreads();
+    const double den = 2.0 * (double)(sigma * sigma);          // 2.0*SQR(sigma), SQR in float (channel.h:13)
+    const int spl = q / 64;                                    // images per lane
+    for (size_t v = (size_t)blockIdx.x * 4 + wave; v < nvn; v += (size_t)gridDim.x * 4) {
+        float y[4], a[4];
+        for (int d = 0; d < D; ++d) {
+            y[d] = obs[v * D + d];
+            a[d] = (mode == 1) ? att[v * D + d] : 1.0f;
+        }
+        for (int h = 0; h < spl; ++h) {
+            const int img = lane + 64 * h;
+            const float *t = tab + img * D;
+            float tmp;
+            if (mode == 0) {
+                const float e0 = y[0] - t[0], e1 = y[1] - t[1];
+                tmp = (float)((double)(e0 * e0) / den + (double)(e1 * e1) / den);
+            } else {
+                tmp = 0.0f;
+                for (int d = 0; d < D; ++d)
+                    if (a[d] > 0) {
+                        const float e = y[d] - a[d] * t[d];
+                        tmp = (float)((double)tmp + (double)(e * e) / den);
+                    }
+            }
+            row[wave][b2i[img]] = tmp;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float *dst = app + v * q;
+        if (spl == 4) *reinterpret_cast<float4 *>(dst + 4 * lane) = *reinterpret_cast<const float4 *>(&row[wave][4 * lane]);
+        else dst[lane] = row[wave][lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // NB_LDPC.c:479-485: bit errors between decide[k] and the codeword over the first K symbols
 __global__ void k_count_errors(const uint8_t *__restrict__ decide, const int *__restrict__ cw, int N, int K,
                                const uint8_t *__restrict__ idx2bin, int *__restrict__ nberr)
@@ -2172,7 +2228,10 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     const bool g0 = lane < 16;
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
     if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
-        es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3));
+    {
+        ST_DUMMY
+        es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3) ST_ARGS);
+    }
     else es_stage(lists, lens, lane, g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, g0 ? 2 : -1, nm, nbOper);
     wave_lds_sync();
     for (int k = lane; k < nm; k += 64) {
@@ -2211,7 +2270,8 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     Cfg C;
     C.dc = dc; C.nm = nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, nm + 3); C.q = Q; C.nsteps = dc - 2;
     C.n_lists = P.n_lists; C.offset = P.offset;
-    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull);
+    ST_DUMMY
+    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull ST_ARGS);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
         const EmsEntry *ol = lists + oid * nmp;
@@ -2374,6 +2434,15 @@ hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, in
     size_t blocks = (nvn + per - 1) / per;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_llr_init, dim3((unsigned)blocks), dim3(256), 0, st, noisy_dev, sigma, logq, q, nvn, idx2bin_dev, bin2idx_dev, app_dev);
+    return hipGetLastError();
+}
+
+hipError_t ems_launch_llr_const(const float *obs_dev, const float *att_dev, const float *table_dev, int q, int D, int mode, float sigma,
+                                size_t nvn, const uint8_t *bin2idx_dev, float *app_dev, hipStream_t st)
+{
+    size_t blocks = (nvn + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_llr_const, dim3((unsigned)blocks), dim3(256), 0, st, obs_dev, att_dev, table_dev, q, D, mode, sigma, nvn, bin2idx_dev, app_dev);
     return hipGetLastError();
 }
 

@@ -439,6 +439,19 @@ void ModelChannel_AWGN_BPSK(code_t *code, decoder_t *decoder, table_t *table, in
     }
 }
 
+void ModelChannelLLR(code_t *code, decoder_t *decoder, const float *obs, const float *att, const float *table, int D, int mode,
+                     float sigma)
+{
+    Ctx *c = nullptr;
+    int rc = get_ctx(code, decoder->nbMax, 2, 2 * decoder->nbMax, 0.f, &c);
+    if (!rc) rc = ems_llr_init_constellation(c->h, obs, att, table, D, mode, sigma, 1);
+    if (!rc) rc = ems_get_sorted_llr(c->h, 0, decoder->intrinsic_LLR[0], decoder->intrinsic_GF[0]);
+    if (rc) {
+        complain("ModelChannelLLR", rc);
+        exit(EXIT_FAILURE); // void signature, as ModelChannel_AWGN_BPSK: never continue on stale LLRs
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // check node, decision, syndrome: device-backed single-node calls
 // ---------------------------------------------------------------------------------------------------

@@ -92,6 +92,19 @@ class RefSession:
         return (block(self.dec.intrinsic_LLR, self.N, self.GF, np.float32).copy(),
                 block(self.dec.intrinsic_GF, self.N, self.GF, np.int32).copy())
 
+    def model_channel_llr(self, obs, att, table, mode, sigma):
+        """ModelChannelLLR (NEW: the LLR + sort part of the constellation front ends, channel.c:270-304 / :676-730 /
+        :861-915): fills decoder.intrinsic_LLR / intrinsic_GF from one frame's observations."""
+        obs = np.ascontiguousarray(obs, np.float32)
+        table = np.ascontiguousarray(table, np.float32)
+        att = None if att is None else np.ascontiguousarray(att, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.L.ModelChannelLLR.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        self.L.ModelChannelLLR.restype = None
+        self.L.ModelChannelLLR(C.byref(self.code), C.byref(self.dec), fp(obs), fp(att), fp(table), obs.shape[1], mode, C.c_float(sigma))
+        return (block(self.dec.intrinsic_LLR, self.N, self.GF, np.float32).copy(),
+                block(self.dec.intrinsic_GF, self.N, self.GF, np.int32).copy())
+
     def decoding(self, NbIterMax, NbOper, offset):
         """Decoding() (hoist of NB_LDPC.c:266-472); returns (iter+1, decide, synd)."""
         decide = np.zeros(self.N, np.int32)

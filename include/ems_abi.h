@@ -80,6 +80,18 @@ int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed t
  * noisy: [B][N][logGF] float BPSK+AWGN observations (host-generated so the drand48 stream is kept). */
 int ems_llr_init(ems_handle *h, const float *noisy_host, float sigma, int B);
 int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B);
+/* The constellation front ends of channel.c:112-929 -- LLR part: one GF(q) symbol = one point of a
+ * D-dimensional constellation (D = 2: 64-APSK, rotated 64/256-QAM; D = 4: the 4-D 256-QAM), q = 64 or 256.
+ *   obs   [B][N][D]  received coordinates (the reference's NoisyBin, channel.c:255-266 / :636-670 / :829-856)
+ *   att   [B][N][D]  per-axis attenuation as the LLR sees it (fading, 0 = erased axis); NULL with EMS_LLR_SUM
+ *   table [q][D]     the normalised constellation, indexed by the symbol's BINARY IMAGE (the reference's `som`)
+ *   mode  EMS_LLR_SUM: SQR(y0-t0)/(2 sigma^2) + SQR(y1-t1)/(2 sigma^2), both quotients double, one rounding (channel.c:277)
+ *         EMS_LLR_SSD: axes with attenuation > 0 accumulate SQR(y-a*t)/(2 sigma^2) into a float, others are skipped
+ *                      (channel.c:690-700, :870-886) -- a node with every axis erased gets an all-zero row
+ * The draws (RNG, modulation, fading, erasures) stay on the harness side, as for ems_llr_init. */
+enum { EMS_LLR_SUM = 0, EMS_LLR_SSD = 1 };
+int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, int D, int mode,
+                               float sigma, int B);
 /* Alternative input for tests: load APP directly from [B][N][GF] LLRs indexed by symbol. */
 int ems_load_llr(ems_handle *h, const float *llr_host, int B);
 

@@ -88,6 +88,15 @@ void Decision(int *decision, float **APP, int N, int GF);                       
 void ModelChannel_AWGN_BPSK(code_t *code, decoder_t *decoder, table_t *table, int **NBIN, float EbN,
                             int *init_rand);
 
+/* ---- NEW: the LLR + sort part of the constellation front ends -- ModelChannel_AWGN_64 (channel.c:270-304),
+ *      ModelChannel (:676-730) and ModelChannel_AWGN_256QAM_4D (:861-915) -- hoisted into one function (SURVEY.md
+ *      8(f) row f3).  The draws, the constellation construction and its normalisation stay where they are in
+ *      channel.c; INTEGRATION.md section 5 shows the three-line forward.  obs / att: [N][D] flat (NoisyBin rows,
+ *      attenuation[n][d]; att may be NULL with mode EMS_LLR_SUM), table: [GF][D] indexed by the binary image `som`,
+ *      mode: EMS_LLR_SUM (0) or EMS_LLR_SSD (1) of ems_abi.h.  Fills decoder->intrinsic_LLR / intrinsic_GF. ---- */
+void ModelChannelLLR(code_t *code, decoder_t *decoder, const float *obs, const float *att, const float *table, int D,
+                     int mode, float sigma);
+
 /* ---- bubble_decoder.h:15-17,26 ---- */
 int maximum(float *Y, int nl);                                                             /* host helper */
 int minimum(float *Y, int nl);                                                             /* host helper */

@@ -109,4 +109,14 @@ uint32_t orc_crc32(const void *buf, uint64_t len);
 #ifdef __cplusplus
 }
 #endif
+/* ---- constellation channel front ends (ems_channel_oracle.c; channel.c:112-929) ---- */
+void orc_const_normalise(float *table /*[q][D] in place*/, int q, int D);                /* channel.c:206-221, :565-577, :791-807 */
+void orc_const_rotate(const float *qam /*[q][2]*/, int q, float *out /*[q][2]*/);        /* channel.c:347-358 (QAM_R)            */
+void orc_const_apsk64(const double *radius, const int *num, const int *den, float *out /*[64][2]*/); /* channel.c:132-199 */
+float orc_chan_sigma(float EbN);                                                         /* channel.c:233 / :596 / :810          */
+void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const int *images, float sigma,
+                   float *obs /*[N][D]*/, float *att /*[N][D]*/);
+void orc_const_llr(const orc_gf *gf, const float *table, int q, int D, int mode, const float *obs, const float *att, int N,
+                   float sigma, float *llr /*[N][q]*/);
+
 #endif

@@ -17,7 +17,7 @@ REF_DIR = os.path.join(HERE, "_ref")
 
 def build(force=False):
     """Compile the restatement (and the real reference when /root/reference exists)."""
-    src = [os.path.join(HERE, f) for f in ("ems_oracle.c", "ems_oracle.h", "ems_v2_oracle.c", "ems_source_oracle.c")]
+    src = [os.path.join(HERE, f) for f in ("ems_oracle.c", "ems_oracle.h", "ems_v2_oracle.c", "ems_source_oracle.c", "ems_channel_oracle.c")]
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if stale:

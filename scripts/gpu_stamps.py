@@ -27,6 +27,11 @@ for w in (sys.argv[1:] or ["gf256"]):
     for grp, lab in ((0, "waves 0-8"), (8, "waves 9-15")):
         tot = float(st[grp:grp + 8].sum()) or 1.0
         print("  %s: " % lab + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[grp + i]) / tot) for i in range(8)))
+    sub = ["ES prologue (+stage overhead)", "ES merge loop", "ES tie check", "ES post-pass + continuation"]
+    if float(st[8:12].sum()) > 0:   # the two-visit kernel reports everything in slots 0..7 and ES sub-phases in 8..11
+        tot = float(st[:16].sum())
+        print("  two-visit kernel, share of all wave time: " + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[i]) / tot) for i in range(8))
+              + " | " + ", ".join("%s %.1f%%" % (sub[i], 100.0 * float(st[8 + i]) / tot) for i in range(4)))
     print("  share of all wave time: " + ", ".join("%s %.1f%%" % (names[i], 100.0 * float(st[i] + st[8 + i]) / float(st[:16].sum())) for i in range(8)))
     w0 = st[0:8].astype(np.float64); nw = int(os.environ.get("EMS_WAVES", "9")) * B if os.environ.get("EMS_WAVES") else 9 * B
     per_wave_cycles = w0.sum() / nw

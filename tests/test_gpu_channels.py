@@ -1,0 +1,143 @@
+"""GPU parity of the constellation channel front ends (channel.c:112-929): k_llr_const through
+ems_llr_init_constellation / ModelChannelLLR against the oracle and against outputs of the REAL reference functions
+(tests/golden/channel_const.npz), then whole decodes fed by these front ends."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import MAT, ROOT, gold
+
+pytestmark = pytest.mark.gpu
+CASES = [("apsk64_n96", "apsk64", "N96_K48_GF64"), ("qamr64_n96", "qamr_ssd", "N96_K48_GF64"),
+         ("qamr256_big", "qamr_ssd", "Ahmed_64800_R12_GF256"), ("qam4d_big", "qam4d", "Ahmed_64800_R12_GF256")]
+
+
+@pytest.fixture(scope="module")
+def chan(orc):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    return importlib.import_module("orc_chan")
+
+
+def _frames(orc, ch, o, sigma, n, seed=5):
+    rng = orc.Rng(seed)
+    out = []
+    for _ in range(n):
+        cw, _noisy = o.draw_frame(rng, 0.7)               # a codeword of the code (the BPSK samples are not used)
+        obs, att = ch.draw(rng, cw, sigma)
+        out.append((cw, obs, att))
+    return out
+
+
+@pytest.mark.parametrize("tag,kind,matrix", CASES)
+def test_llr_matches_reference_outputs(pkg, orc, chan, tag, kind, matrix):
+    """The fixture's frame (same codeword, same drand48 stream as the reference function saw): every LLR the kernel
+    writes, and the sorted rows ems_get_sorted_llr builds from them, equal decoder.intrinsic_LLR / intrinsic_GF of the
+    real function (head rows in full, CRC-32 of the whole blocks)."""
+    raw = gold("channel_const.npz")
+    q = 64 if "N96" in matrix else 256
+    ch = chan.Channel(kind, q, raw)
+    sigma = ch.sigma(float(raw[tag + "_ebn"]))
+    obs, att = ch.draw(orc.Rng(0), raw[tag + "_cw"].astype(np.int32), sigma)
+    dec = pkg.Decoder(pkg.Code(os.path.join(MAT, matrix)), 8, 16, 0.3, 4, max_batch=1)
+    dec.llr_init_constellation(obs[None], None if ch.mode == chan.MODE_SUM else att[None], ch.table, ch.mode, sigma)
+    dec.synchronize()
+    assert dec.app(0).tobytes() == ch.llr(obs, att, sigma).tobytes()
+    sl, sg = dec.sorted_llr(0)
+    head = raw[tag + "_llr_head"].shape[0]
+    assert sl[:head].tobytes() == raw[tag + "_llr_head"].tobytes() and (sg[:head] == raw[tag + "_gf_head"]).all()
+    assert orc.crc32(sl) == int(raw[tag + "_crc"][0]) and orc.crc32(sg.astype(np.int32)) == int(raw[tag + "_crc"][1])
+    dec.close()
+
+
+@pytest.mark.parametrize("kind,matrix,ebn,nm,B", [("apsk64", "N96_K48_GF64", 9.0, 16, 40), ("qamr_ssd", "N96_K48_GF64", 15.0, 16, 40),
+                                                  ("qamr_ssd", "Ahmed_64800_R12_GF256", 23.0, 20, 3), ("qam4d", "Ahmed_64800_R12_GF256", 13.0, 20, 3)])
+def test_decode_behind_constellation_front_ends(pkg, orc, chan, kind, matrix, ebn, nm, B):
+    """Batches through the front end and the layered decode: APP rows of the init, then decisions, iterations,
+    syndromes and the final APP against the oracle fed with the oracle's LLRs."""
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, matrix)
+    o = orc.Oracle(path)
+    ch = chan.Channel(kind, o.q, raw)
+    sigma = ch.sigma(ebn)
+    fr = _frames(orc, ch, o, sigma, B)
+    obs = np.stack([f[1] for f in fr]); att = np.stack([f[2] for f in fr])
+    dec = pkg.Decoder(pkg.Code(path), nm, 2 * nm, 0.3, 8, max_batch=B)
+    dec.llr_init_constellation(obs, None if ch.mode == chan.MODE_SUM else att, ch.table, ch.mode, sigma)
+    dec.decode(B)
+    d, it, sy = dec.results(B)
+    nconv = 0
+    for b in range(B):
+        ref = o.decode(ch.llr(obs[b], att[b], sigma), nm, 2 * nm, 0.3, 8, want_state=True)
+        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], "frame %d" % b
+        assert dec.app(b).tobytes() == ref["app"].tobytes()
+        nconv += int(sy[b] == 0 and (d[b] == fr[b][0]).all())
+    assert nconv >= 1                                      # the operating points are decodable: the chain is not vacuous
+    dec.close()
+
+
+def test_erasures_edge_cases(pkg, orc, chan):
+    """Every axis of a node erased (all-zero LLR row: the top-nm selection falls back to its literal path), one axis
+    erased, and a batch position that differs only in its attenuations."""
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    ch = chan.Channel("qamr_ssd", 64, raw)
+    sigma = ch.sigma(16.0)
+    (cw, obs, att), = _frames(orc, ch, o, sigma, 1, seed=9)
+    att2 = att.copy(); att2[3] = 0.0; att2[7, 0] = 0.0; att2[8, 1] = 0.0
+    att3 = np.zeros_like(att)
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 6, max_batch=3)
+    dec.llr_init_constellation(np.stack([obs, obs, obs]), np.stack([att, att2, att3]), ch.table, ch.mode, sigma)
+    dec.decode(3)
+    d, it, sy = dec.results(3)
+    for b, a in enumerate((att, att2, att3)):
+        llr = ch.llr(obs, a, sigma)
+        if b == 2:
+            assert (llr == 0).all()
+        ref = o.decode(llr, 16, 32, 0.3, 6, want_state=True)
+        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"]
+        assert dec.app(b).tobytes() == ref["app"].tobytes()
+    dec.close()
+
+
+def test_reference_shaped_model_channel_llr_then_decoding(pkg, orc, chan, refapi):
+    """ModelChannelLLR -> Decoding() on the reference's own structs (what the patched channel.c of INTEGRATION.md
+    section 5 calls), frame after frame."""
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    s = refapi.RefSession(path, 16)
+    for kind, ebn in (("apsk64", 10.0), ("qamr_ssd", 15.0)):
+        ch = chan.Channel(kind, 64, raw)
+        sigma = ch.sigma(ebn)
+        for cw, obs, att in _frames(orc, ch, o, sigma, 4, seed=21):
+            sl, sg = s.model_channel_llr(obs, None if ch.mode == chan.MODE_SUM else att, ch.table, ch.mode, sigma)
+            llr = ch.llr(obs, att, sigma)
+            osl, osg = o.sort_llr(llr)
+            assert sl.tobytes() == osl.tobytes() and (sg == osg).all()
+            it, decide, synd = s.decoding(10, 32, 0.3)
+            ref = o.decode(llr, 16, 32, 0.3, 10, want_state=True)
+            assert it == ref["iters"] and synd == ref["synd"] and (decide == ref["decide"]).all()
+            assert s.APP.tobytes() == ref["app"].tobytes()
+    s.close()
+
+
+def test_front_end_argument_checks(pkg):
+    dec = pkg.Decoder(pkg.Code(os.path.join(MAT, "N96_K48_GF64")), 16, 32, 0.3, 6, max_batch=1)
+    obs = np.zeros((1, 16, 2), np.float32); tab = np.zeros((64, 2), np.float32)
+    with pytest.raises(pkg.EmsError) as e:
+        dec.llr_init_constellation(obs, None, tab, pkg.LLR_SSD, 0.3)          # SSD needs attenuations
+    assert e.value.code == pkg.EMS_EINVAL
+    with pytest.raises(pkg.EmsError):
+        dec.llr_init_constellation(obs, None, tab, pkg.LLR_SUM, 0.0)          # sigma
+    with pytest.raises(pkg.EmsError):
+        dec.llr_init_constellation(np.zeros((1, 16, 4), np.float32), None, np.zeros((64, 4), np.float32), pkg.LLR_SUM, 0.3)   # SUM is 2-D
+    dec.close()
+    d16 = pkg.Decoder(pkg.Code(os.path.join(MAT, "Ahmed_64800_R34_GF16")), 8, 16, 0.3, 4, max_batch=1)
+    with pytest.raises(pkg.EmsError) as e:
+        d16.llr_init_constellation(np.zeros((1, d16.code.N, 2), np.float32), None, np.zeros((16, 2), np.float32), pkg.LLR_SUM, 0.3)
+    assert e.value.code == pkg.EMS_EUNSUPPORTED
+    d16.close()
