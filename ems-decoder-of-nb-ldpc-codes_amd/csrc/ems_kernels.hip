@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     constexpr int NREC = (EMS_MAX_NM + LPE - 1) / LPE;
     float mvc[G::EPL];
     float hint = __builtin_inff();
-    if constexpr (DUAL && Geo<Q, LPE>::VW == 4) load_row_nt<Q, LPE>(app_row, rl, mvc);
+    if constexpr (DUAL && Q >= 256) load_row_nt<Q, LPE>(app_row, rl, mvc);      // (small fields: the whole APP block lives in the caches, n96 lost 3 % with it)
     else load_row<Q, LPE>(app_row, rl, mvc);
     if (!first_sweep) {
         const float dflt = *reinterpret_cast<const float *>(rec + EMS_REC_DFLT(nm));
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     else load_row<Q, LPE>(drow, rl, napp);
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) napp[e] = napp[e] + mvc[e];
-    if constexpr (DUAL && Geo<Q, LPE>::VW == 4) { if (stact) store_row_nt<Q, LPE>(app_row, rl, napp); }
+    if constexpr (DUAL && Q >= 256) { if (stact) store_row_nt<Q, LPE>(app_row, rl, napp); }
     else if (stact) store_row<Q, LPE>(app_row, rl, napp);
 
     // ---- Decision (tools.c:312-330) of this variable node; the later visit of the sweep wins ----
