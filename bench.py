@@ -179,8 +179,40 @@ def cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads):
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(one, frames))
     dt = time.time() - t0
-    return {"value": round(threads / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d frames (1 per thread), same workload, fixed work, LLR init + 29 sweeps, %.1f s wall" % (threads, dt)}
+    out = {"value": round(threads / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "%d frames (1 per thread), same workload, fixed work, LLR init + 29 sweeps, %.1f s wall" % (threads, dt)}
+    ref = reference_executable_rate(orc, matrix, nm, nop, off, itmax, ebn, threads)
+    if ref:
+        out["reference_executable"] = ref
+    return out
+
+
+def reference_executable_rate(orc, matrix, nm, nop, off, itmax, ebn, procs, frames_each=2):
+    """The REAL reference (oracle/_ref/essai_ubs, compiled from /root/reference by oracle/Makefile; travels to the GPU box as a
+    built binary) timed beside the port: `procs` copies of the executable, one per core, `frames_each` frames each of the
+    same workload (its whole per-frame path: source, encoder, channel, decode; the one-off set-up of every process --
+    loader, tables, Gaussian elimination -- is inside the wall time).  None when the binary is not there."""
+    import subprocess
+    exe = orc.ref_binary("ubs")
+    if not os.path.exists(exe):
+        return None
+    run = os.path.join(os.path.dirname(exe), "run")
+    os.makedirs(os.path.join(run, "data"), exist_ok=True)
+    cmd = [exe, str(frames_each), str(itmax), matrix, str(ebn), str(nm), str(off), str(nop)]
+    t0 = time.time()
+    ps = [subprocess.Popen(cmd, cwd=run, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
+    for p in ps:
+        try:
+            p.communicate(b"\n", timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            return None
+    dt = time.time() - t0
+    if any(p.returncode != 0 for p in ps):
+        return None
+    return {"value": round(procs * frames_each / dt, 4), "unit": "frames/s", "cores": procs, "kind": "reference",
+            "sample": "%d processes x %d frames of the reference executable (early exit on, %.1f dB: every frame runs all %d sweeps), %.1f s wall incl. its set-up"
+                      % (procs, frames_each, ebn, itmax - 1, dt)}
 
 
 class c_stdout_to_stderr:
