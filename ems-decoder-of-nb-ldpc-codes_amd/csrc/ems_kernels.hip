@@ -445,7 +445,7 @@ __device__ __forceinline__ bool es_post(const EmsEntry *in1, const EmsEntry *in2
             lim = min(lim, li);
         }
     }
-    lim = redT_mini<TL>(lim);
+    if (__ballot(lim < (1 << 20)) != 0ull) lim = redT_mini<TL>(lim);   // (no lane of the wave saw a stop: nothing to reduce)
     bool stopped = lim <= T;
     lim = min(lim, T);
     wave_lds_sync();
@@ -520,7 +520,6 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     const int gsel = lane / TL;
     const bool has = (task.y >> 16) != 0u;          // see es_task(): byte offsets of the lists, output id + 1
     const int o_id = (int)(task.y >> 16) - 1;
-    const int nmp = list_stride(nm);
     uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
     const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (task.x & 0xFFFFu));
     const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (task.x >> 16));
@@ -529,10 +528,8 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     uint8_t *picks = picks_base + gsel * (ES_MAX_STEPS + 4);            // pick areas 17 dwords apart (bank spread); lanes without a task scribble in theirs
     uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;  // one dword per lane: no same-dword byte writes
 
-    if (has) {
-#pragma unroll 3
-        for (int k = p16; k < nmp; k += TL) out[k] = EmsEntry{k < nm ? EMS_SENTINEL : __builtin_inff(), EMS_S_INVALID}; // :370-374
-    }
+    // (Output = (1e5, -1) everywhere, bubble_decoder.c:370-374: only the tail behind the S entries emitted can show through,
+    //  and S = nm nearly always -- the tail is written at the end, when there is one, and so are the two pads.)
 
     const bool rowc = p < 4;
     const EmsEntry *mv = rowc ? in2 : in1;
@@ -571,6 +568,11 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
         es_post_rt<0, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
     }
+    if (__ballot(has && S < nm) != 0ull) {                        // a short output (rare): the initial fill behind it
+        if (has)
+            for (int k = S + p16; k < nm; k += TL) out[k] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID};
+    }
+    if (has && p16 < 2) out[nm + p16] = EmsEntry{__builtin_inff(), EMS_S_INVALID};   // list pads (scratch of other phases may have been here)
     STAMP(11);
     if (has && p16 == 0) lens[o_id] = S;
 }
@@ -1432,7 +1434,12 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decod
     C.dc = DUAL_DC;
     C.nm = NM > 0 ? NM : P.nm;
     C.nbOper = P.nbOper;
-    C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);          // the specialised kernels require nbOper >= nm+3
+#ifndef EMS_T1X
+#define EMS_T1X 5
+#endif
+    // first-pass length of the merge: nm + 3 picks; GF(16) sees so many duplicate symbols (16 symbols, 8 wanted) that a third
+    // of the stages needed the 8-step continuation -- a longer first pass is cheaper there
+    C.T1 = NM > 0 ? min(P.nbOper, NM + (Q == 16 ? EMS_T1X : 3)) : min(P.nbOper, P.nm + 3);   // (specialised kernels: nbOper >= nm+3)
     C.q = Q;
     C.nsteps = DUAL_DC - 2;
     C.n_lists = DUAL_NLISTS;
