@@ -37,7 +37,7 @@ WORKLOADS = {
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
     # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
     # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (synthetic_likelihood below, sigma 0.95)
-    "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1024),
+    "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1536),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -143,7 +143,7 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
                "config": {"workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
                           "batch_per_gpu": B, "sharding": "independent frames", "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
                           "frames_nonzero_syndromes_sumiter": counters.cpu().tolist()},
-               "roofline": {"bound": "hbm", "kernel": "k_decode_v2 (persistent, 1 workgroup per frame, %d frames per launch)" % B,
+               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % ("k_decode_v2_dual" if (B + 255) // 256 >= 5 and os.environ.get("EMS_DUAL") != "0" else "k_decode_v2", B),
                             "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
                             "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
                "host_setup_s": round(t_setup, 1)}

@@ -181,7 +181,8 @@ struct ems_handle {
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
-    std::vector<int> p_cn, p_vn, p_lh, p_pred;   // check nodes in pairs (k_decode_dual), see build_pairs
+    std::vector<int> p_cn, p_vn, p_lh, p_pred, p_task;   // check nodes in pairs (k_decode_dual), see build_pairs; p_task: task index per (pair, member), -1 = none
+    std::vector<int> v2_p_dst, v2_p_last;
     int n_pairs = 0;   // iso_vn: variable nodes no check node touches
     std::vector<uint8_t> cn_lh, i2b, b2i;
     CnSchedule cs;
@@ -194,7 +195,7 @@ struct ems_handle {
     std::vector<int> v2_t_dst, v2_vn_edge;
     std::vector<uint8_t> v2_t_last;
     DevBuf<uint8_t> d_v2_t_last;
-    DevBuf<int> d_v2_t_dst, d_v2_vn_edge, d_v2_stage_idx, d_v2_bad;
+    DevBuf<int> d_v2_t_dst, d_v2_vn_edge, d_v2_stage_idx, d_v2_bad, d_v2_p_dst, d_v2_p_last;
     DevBuf<float> d_v2_like, d_v2_vtoc, d_v2_ctov, d_v2_hint, d_v2_app, d_v2_stage_like;
     DevBuf<uint8_t> d_v2_vtoci;
     DevBuf<int16_t> d_v2_ctovi;
@@ -305,11 +306,13 @@ void build_pairs(ems_handle *h)
     h->n_pairs = NP;
     const size_t R = 2 * (size_t)dc;                              // edge rows of a pair
     h->p_cn.assign((size_t)NP * 2, 0); h->p_vn.assign(NP * R, 0); h->p_lh.assign(NP * R, 0); h->p_pred.assign(NP * R, -1);
+    h->p_task.assign((size_t)NP * 2, -1);
     for (int i = 0; i < NP; ++i) {
         const int a = pairs[i].first, b = pairs[i].second;
         const int prio = std::max((h->t_cnp[a] >> 24) & 3, b >= 0 ? (h->t_cnp[b] >> 24) & 3 : 0);
         for (int m = 0; m < 2; ++m) {
             const int t = (m == 1 && b >= 0) ? b : a;          // a single's second half repeats the first, flagged
+            h->p_task[(size_t)i * 2 + m] = t;
             h->p_cn[(size_t)i * 2 + m] = (h->t_cnp[t] & 0xFFFFFF) | (prio << 24) | ((m == 1 && b < 0) ? (1 << 30) : 0);
             for (int k = 0; k < dc; ++k) {
                 const size_t src = (size_t)t * dc + k, dst = (size_t)i * R + (size_t)m * dc + k;
@@ -511,6 +514,7 @@ void ems_destroy(ems_handle *h)
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
+    h->d_v2_p_dst.release(); h->d_v2_p_last.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
@@ -981,8 +985,22 @@ static int v2_prepare(ems_handle *h)
             h->v2_t_last[(size_t)i * h->dc + k] = (e == b) ? 1 : 0;          // edges are numbered in visiting order: the higher one comes last
         }
     }
+    if (h->n_pairs > 0 && h->dc == 4) {                                  // the same two tables by (pair, row) for k_decode_v2_dual
+        const size_t R = 2 * (size_t)h->dc;
+        h->v2_p_dst.assign((size_t)h->n_pairs * R, 0);
+        h->v2_p_last.assign((size_t)h->n_pairs * R, 0);
+        for (int i = 0; i < h->n_pairs; ++i)
+            for (int m = 0; m < 2; ++m) {
+                const int t = h->p_task[(size_t)i * 2 + m];
+                for (int k = 0; k < h->dc; ++k) {
+                    h->v2_p_dst[(size_t)i * R + (size_t)m * h->dc + k] = h->v2_t_dst[(size_t)t * h->dc + k];
+                    h->v2_p_last[(size_t)i * R + (size_t)m * h->dc + k] = h->v2_t_last[(size_t)t * h->dc + k];
+                }
+            }
+    }
     const size_t B = (size_t)h->max_batch, nm = (size_t)h->nm_alloc;
     int r;
+    if ((r = h->d_v2_p_dst.upload(h->v2_p_dst)) || (r = h->d_v2_p_last.upload(h->v2_p_last))) return r;
     if ((r = h->d_v2_t_dst.upload(h->v2_t_dst)) || (r = h->d_v2_t_last.upload(h->v2_t_last)) || (r = h->d_v2_vn_edge.upload(h->v2_vn_edge)) || (r = h->d_v2_like.alloc(B * h->N * h->q)) ||
         (r = h->d_v2_app.alloc(B * h->N * h->q)) || (r = h->d_v2_vtoc.alloc(B * h->E * nm)) || (r = h->d_v2_ctov.alloc(B * h->E * nm)) ||
         (r = h->d_v2_vtoci.alloc(B * h->E * nm)) || (r = h->d_v2_ctovi.alloc(B * h->E * nm)) || (r = h->d_v2_hint.alloc(B * h->E)) ||
@@ -1036,6 +1054,18 @@ int ems_v2_decode(ems_handle *h, int B)
     if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     EmsPlan P = h->plan;
     shape_for_batch(h, B, P, false);                                    // 4-wave workgroups, 3 frames per CU, for big batches
+    P.p_dst = h->d_v2_p_dst.n ? h->d_v2_p_dst.p : nullptr; P.p_last = h->d_v2_p_last.n ? h->d_v2_p_last.p : nullptr;
+    {   // five or more frames per CU: the two-visits-per-wave kernel (2-wave workgroups, six to a CU), as the main path
+        const char *ed = getenv("EMS_DUAL");
+        const long fpc = h->n_cu > 0 ? ((long)B + h->n_cu - 1) / h->n_cu : 0;
+        const bool want = ed ? atoi(ed) > 0 : fpc >= 5;
+        if (want && !getenv("EMS_WAVES") && ems_has_v2_dual_kernel(P) &&
+            6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= (size_t)160 * 1024) {
+            P.dual = 1; P.occ4 = 0;
+            P.waves_per_wg = ed && atoi(ed) > 0 ? std::min(4, atoi(ed)) : 2;
+            P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
+        }
+    }
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
     P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;

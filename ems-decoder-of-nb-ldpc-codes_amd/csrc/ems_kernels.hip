@@ -1651,12 +1651,13 @@ __device__ __forceinline__ int red4_sumi(int x)
 // v2.c:1620-1631 / :1682-1688) does not depend on the output bookkeeping, so a serial merge records the picks and
 // a parallel post-pass applies the stops (:1653 invalid -> before the pick, :1669 nm outputs, :1674 last row/column
 // -> after it) and the redundancy control (:1662).  A task owns 16 lanes; every aligned group of 4 runs the merge.
+template <int TL = 16>
 __device__ __forceinline__ void es_stage_fast_v2(EmsEntry *lists, int *lens, unsigned *tbl_base, uint8_t *picks_base, int q,
                                                  int lane, uint2 task, int nm, int nbOper, int T1)
 {
     const int p = lane & 3;                         // competitor
     const int gbase = lane & ~3;
-    const int p16 = lane & 15, gbase16 = lane & ~15, gsel = lane >> 4;
+    const int p16 = lane & (TL - 1), gbase16 = lane & ~(TL - 1), gsel = lane / TL;   // TL lanes per task (8: two visits per wave)
     const bool has = (task.y >> 16) != 0u;
     const int o_id = (int)(task.y >> 16) - 1;
     const int nmp = list_stride(nm);
@@ -1668,7 +1669,7 @@ __device__ __forceinline__ void es_stage_fast_v2(EmsEntry *lists, int *lens, uns
     uint8_t *picks = picks_base + gsel * (ES_MAX_STEPS + 4);
     uint8_t *dummy = picks_base + 8 * (ES_MAX_STEPS + 4) + lane * 4;
     if (has)
-        for (int k = p16; k < nmp; k += 16) out[k] = EmsEntry{k < nm ? V2_INVALID_V : -__builtin_inff(), EMS_S_INVALID};   // :1590-1593
+        for (int k = p16; k < nmp; k += TL) out[k] = EmsEntry{k < nm ? V2_INVALID_V : -__builtin_inff(), EMS_S_INVALID};   // :1590-1593
     const bool rowc = p < 2;
     const EmsEntry *mv = rowc ? in2 : in1;
     const EmsEntry *mvy = mv - 32 * p;
@@ -1689,30 +1690,39 @@ __device__ __forceinline__ void es_stage_fast_v2(EmsEntry *lists, int *lens, uns
         es_merge<true, 1>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     }
     int Td = T1;
-    if (T1 <= 16) done = es_post<1, 1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else if (T1 <= 32) done = es_post<2, 1>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
-    else done = es_post_rt<1>(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
+    if (T1 <= TL) done = es_post<1, 1, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (T1 <= 2 * TL) done = es_post<2, 1, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (TL == 8 && T1 <= 24) done = es_post<3, 1, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else if (TL == 8 && T1 <= 32) done = es_post<4, 1, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
+    else done = es_post_rt<1, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
     if (__ballot(has && !done) != 0ull) {
         es_merge<true, 1>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
-        es_post_rt<1>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
+        es_post_rt<1, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, nbOper, nm, nbOper, S);
     }
     wave_lds_sync();
     const float last = (has && S > 0) ? out[S - 1].v : 0.0f;         // :1692-1693 normalisation to the last valid entry
     wave_lds_sync();
     if (has)
-        for (int k = p16; k < S; k += 16) out[k].v = out[k].v - last;
+        for (int k = p16; k < S; k += TL) out[k].v = out[k].v - last;
     if (has && p16 == 0) lens[o_id] = S;
 }
 
-template <int Q, int LPE>
+// DUAL (dc = 4, rows of 8 lanes): two visits per wave, as process_cn<.., DUAL> -- rows 0..3 / 4..7, 8-lane elementary-step
+// tasks of both visits in one merge loop; dst / lastf are then this lane's entries of the pair tables (p_dst, p_last) and
+// gact = false masks the HBM stores of a half without a visit of its own.
+template <int Q, int LPE, bool DUAL = false>
 __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, int f, int cn, int task, int vn, int lh,
                                               const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
-                                              EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane)
+                                              EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane,
+                                              int dst_in = 0, bool last_in = false, bool gact = true)
 {
     using G = Geo<Q, LPE>;
+    static_assert(!DUAL || LPE == 8, "two visits per wave: dc = 4, rows of 8 lanes");
+    constexpr int TL = DUAL ? 8 : 16;
     const int rl = lane & (LPE - 1), row = lane / LPE;
-    const bool rowact = row < C.dc;
-    const int t = rowact ? row : C.dc - 1;
+    const int half = DUAL ? row >> 2 : 0;
+    const bool rowact = DUAL ? gact : row < C.dc;              // gates the HBM stores (in DUAL every row computes)
+    const int t = DUAL ? (row & 3) : (rowact ? row : C.dc - 1);
     const int nm = C.nm, nmp = list_stride(nm), qm1 = Q - 1;
     const int edge = cn * C.dc + t;
     // frame bases are wave-uniform (scalar registers); per-lane parts are 32-bit offsets
@@ -1729,8 +1739,8 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q, rl, x);
     // ... and so is the OTHER C->V message of the node where this visit closes the node's sweep (APP below): it was
     // written by an earlier visitor, a predecessor of this task, so it is final now
-    const int dst = P.t_dst[task * C.dc + t];
-    const bool lastv = rowact && P.t_last[task * C.dc + t] != 0;
+    const int dst = DUAL ? dst_in : P.t_dst[task * C.dc + t];
+    const bool lastv = rowact && (DUAL ? last_in : P.t_last[task * C.dc + t] != 0);
     const float hint = f_hint[(unsigned)edge];               // search start of the selection at the end of the visit
     constexpr int NPRE = (EMS_MAX_NM + LPE - 1) / LPE;
     float ov[NPRE];
@@ -1744,7 +1754,7 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     }
 
     // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
-    EmsEntry *inl = lists + t * nmp;
+    EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp, 4) : t * nmp);
     for (int k = rl; k < nmp; k += LPE) {
         EmsEntry e = EmsEntry{__builtin_inff(), EMS_S_INVALID};
         if (k < nm) {
@@ -1752,7 +1762,7 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
             const int g = f_vtoci[(unsigned)(edge * nm + k)];
             e = EmsEntry{v, (unsigned)t_i2b[gf_mul_log(g, lh, qm1)]};
         }
-        if (rowact) inl[k] = e;
+        if (DUAL || rowact) inl[k] = e;
     }
     wave_lds_sync();
 
@@ -1760,31 +1770,31 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     unsigned *seen = reinterpret_cast<unsigned *>(dense);
     const bool fast = C.nbOper <= ES_MAX_STEPS;              // pick areas hold 64 steps; longer runs take the literal form
     if (fast) {
-        for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
+        for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
         wave_lds_sync();
-        for (int st = 1; st <= C.nsteps; ++st) {             // 16 lanes per task; the dedupe tables stay clean between stages
-            const uint2 tk = sched[(st - 1) * 8 + (lane >> 4)];
-            es_stage_fast_v2(lists, lens, seen, picks, Q, lane, tk, nm, C.nbOper, C.T1);
+        for (int st = 1; st <= C.nsteps; ++st) {             // TL lanes per task; the dedupe tables stay clean between stages
+            const uint2 tk = sched[(st - 1) * 8 + lane / TL];
+            es_stage_fast_v2<TL>(lists, lens, seen, picks, Q, lane, tk, nm, C.nbOper, C.T1);
             wave_lds_sync();
         }
     }
     for (int st = 1; !fast && st <= C.nsteps; ++st) {
-        for (int i = lane * 4; i < 4 * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
+        for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
         wave_lds_sync();
         const uint2 tk = sched[(st - 1) * 8 + (lane & 7)];
-        const bool has = lane < 4 && (tk.y >> 16) != 0u;
+        const bool has = lane < (DUAL ? 8 : 4) && (tk.y >> 16) != 0u;
         uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
         const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (tk.x & 0xFFFFu));
         const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (tk.x >> 16));
         EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (tk.y & 0xFFFFu));
-        const int s = es_v2_task(in1, in2, out, seen + (lane & 3) * Q, nm, C.nbOper, has);
+        const int s = es_v2_task(in1, in2, out, seen + (lane & (DUAL ? 7 : 3)) * Q, nm, C.nbOper, has);
         if (has) lens[(int)(tk.y >> 16) - 1] = s;
         wave_lds_sync();
     }
 
     // ---- outputs: inverse rotation over the valid prefix (:1854-1870), C->V record (:2135-2141) ----
-    const EmsEntry *ol = lists + oid * nmp;
-    const int stp = (C.dc == 2) ? nm : lens[oid];
+    const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp, 4) : oid * nmp);
+    const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * dual_nlists(4) + oid : oid];
     for (int k = rl; k < nm; k += LPE) {
         const EmsEntry e = ol[k];
         const bool valid = k < stp;
@@ -1847,7 +1857,7 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     wave_lds_sync();
     bool big = false;
     float T_sel = __builtin_inff();
-    if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow)) {
+    if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, DUAL || rowact, big, hint, T_sel, drow)) {
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
     }
     wave_lds_sync();
@@ -1999,6 +2009,120 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
         it = sweep + 1;
         if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
             for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {          // (rows of 16 lanes here, whatever LPE is)
+                const int n = n0 + (lane >> 4);
+                app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + (lane >> 4) * Q, lane & 15, true);
+            }
+        }
+        if ((synd == 0 && P.early_exit)) break;
+    }
+    if (tid == 0) {
+        P.iters[f] = *spin_fail ? -1 : it;
+        P.synd[f] = (int)synd;
+    }
+}
+
+// The v2 decode kernel with TWO check-node visits per wave (dc = 4): k_decode_dual's organisation (pairs claimed in order, one
+// done bit per pair, survivor scratch aliased behind the input lists, 2-wave workgroups six to a CU) around
+// process_cn_v2<.., DUAL>.  The scratch alias holds here too: the variable-node update (DataPassLog) runs its selection
+// AFTER the elementary steps, when the non-input lists, lens and picks are dead.
+template <int Q, int NM>
+__global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
+{
+    constexpr int LPE = 8, DC = 4;
+    constexpr int DUAL_NLISTS = dual_nlists(DC), DUAL_SCHED_BYTES = dual_sched_bytes(DC);
+    Cfg C;
+    C.dc = DC; C.nm = NM > 0 ? NM : P.nm; C.nbOper = P.nbOper; C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);   // (NM > 0: nbOper >= NM + 3)
+    C.q = Q; C.nsteps = DC - 2; C.n_lists = DUAL_NLISTS; C.offset = P.offset;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *t_i2b = smem, *t_b2i = smem + Q;
+    unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);
+    unsigned *next_task = first_bad + 1, *spin_fail = first_bad + 2;
+    uint2 *sched = reinterpret_cast<uint2 *>(smem + 2 * Q + 16);
+    unsigned *done = reinterpret_cast<unsigned *>(smem + 2 * Q + 16 + DUAL_SCHED_BYTES);
+    const int NP = P.n_pairs, ndw = (NP + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.x;
+    const int rl = lane & (LPE - 1), row = lane / LPE, half = row / DC;
+    const int oid = P.out_list[row % DC];
+    const int nmp = list_stride(C.nm);
+    uint8_t *wbase = smem + dual_header_bytes(Q, DC, NP) + (size_t)wave * P.wave_lds_bytes;
+    float *dense = reinterpret_cast<float *>(wbase);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + dual_dense_bytes(Q, DC));
+    uint8_t *other = wbase + dual_dense_bytes(Q, DC) + 2 * DC * nmp * 8;
+    EmsEntry *surv = reinterpret_cast<EmsEntry *>(other);
+    int *lens = reinterpret_cast<int *>(other + 2 * (DUAL_NLISTS - DC) * nmp * 8);
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((2 * DUAL_NLISTS * 4 + 15) & ~15);
+    for (int i = tid; i < Q; i += blockDim.x) { t_i2b[i] = P.idx2bin[i]; t_b2i[i] = P.bin2idx[i]; }
+    for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
+    cn_sched_build_dual(sched, DC, C.nm, tid, blockDim.x);
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
+    __syncthreads();
+
+    int it = 0;
+    unsigned synd = 0;
+    for (int sweep = 0; sweep < P.nsweeps; ++sweep) {                      // iter = 0..NbIterMax (v2.c:2119)
+        auto claim = [&]() {
+            unsigned i = 0;
+            if (lane == 0) i = atomicAdd(next_task, 1u);
+            return (int)__builtin_amdgcn_readfirstlane((int)i);
+        };
+        int cur = claim();
+        int cnw = 0, vn = 0, lh = 0, pred = -1, dst = 0, lastf = 0;
+        if (cur < NP) {
+            cnw = P.p_cn[cur * 2 + half];
+            vn = P.p_vn[cur * 8 + row]; lh = P.p_lh[cur * 8 + row]; pred = P.p_pred[cur * 8 + row];
+            dst = P.p_dst[cur * 8 + row]; lastf = P.p_last[cur * 8 + row];
+        }
+        while (cur < NP) {                                                 // pairs of check nodes in dependency order (:2122)
+            const int nxt = claim();
+            int ncnw = 0, nvn = 0, nlh = 0, npred = -1, ndst = 0, nlastf = 0;
+            if (nxt < NP) {
+                ncnw = P.p_cn[nxt * 2 + half];
+                nvn = P.p_vn[nxt * 8 + row]; nlh = P.p_lh[nxt * 8 + row]; npred = P.p_pred[nxt * 8 + row];
+                ndst = P.p_dst[nxt * 8 + row]; nlastf = P.p_last[nxt * 8 + row];
+            }
+            const bool gact = ((cnw >> 30) & 1) == 0;
+            const int pp = (rl == 0 && gact) ? pred : -1;
+            unsigned spins = 0;
+            for (;;) {
+                const bool ok = pp < 0 || ((__hip_atomic_load(&done[pp >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (pp & 31)) & 1u) != 0u;
+                if (__ballot(!ok) == 0ull) break;
+                if (++spins > (1u << 24)) { if (lane == 0) atomicOr(spin_fail, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            switch ((__builtin_amdgcn_readfirstlane(cnw) >> 24) & 3) {
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            process_cn_v2<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, 0, vn, lh, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, dst, lastf != 0, gact);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicOr(&done[cur >> 5], 1u << (cur & 31));
+            cur = nxt; cnw = ncnw; vn = nvn; lh = nlh; pred = npred; dst = ndst; lastf = nlastf;
+        }
+        __syncthreads();
+        if (tid == 0) *next_task = 0;
+        for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
+        const int nwaves = (int)(blockDim.x >> 6);
+        // ---- Syndrom (:1934-1949): value of the first check with a non-zero sum ----
+        for (int c = tid; c < P.M; c += blockDim.x) {
+            unsigned acc = 0;
+            for (int i = 0; i < DC; ++i) {
+                const int ed = c * DC + i;
+                const int xx = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
+                acc ^= t_i2b[gf_mul_log(xx, P.cn_lh[ed], Q - 1)];
+            }
+            if (acc) atomicMin(first_bad, ((unsigned)c << 8) | t_b2i[acc]);
+        }
+        __syncthreads();
+        const unsigned fb = *first_bad;
+        __syncthreads();
+        if (tid == 0) *first_bad = 0xFFFFFFFFu;
+        synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
+        it = sweep + 1;
+        if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
+            for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {          // (rows of 16 lanes here)
                 const int n = n0 + (lane >> 4);
                 app_decide_v2<Q>(P, C, f, n < P.N ? n : P.N - 1, n < P.N, dense + (lane >> 4) * Q, lane & 15, true);
             }
@@ -2574,8 +2698,17 @@ template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launc
     hipLaunchKernelGGL((k_decode_v2<Q, LPE, NM, OCC4>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
+bool ems_has_v2_dual_kernel(const EmsPlan &P) { return P.q == 256 && P.dc == 4 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && P.n_pairs > 0 && P.p_dst; }
 hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
 {
+    if (P0.dual) {
+        if (!ems_has_v2_dual_kernel(P0) || P0.waves_per_wg > 4 || P0.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P0.q, P0.dc, P0.nm)) return hipErrorInvalidValue;
+        const size_t lds = ems_dual_wg_lds_bytes(P0.q, P0.dc, P0.nm, P0.n_pairs, P0.waves_per_wg);
+        hipError_t e = set_max_lds(k_decode_v2_dual<256, 20>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_decode_v2_dual<256, 20>), dim3(B), dim3(P0.waves_per_wg * 64), lds, st, P0);
+        return hipGetLastError();
+    }
     const int lpe = ems_lpe_for(P0.dc);
     if ((lpe != 16 && lpe != 8 && lpe != 4) || P0.dc < 2) return hipErrorInvalidValue;
     EmsPlan P = P0;

@@ -83,6 +83,8 @@ struct EmsPlan {
     const int *t_dst;       // [M*dc]     per (task, edge): row-order id of the OTHER edge of its variable node (dv = 2)
     const int *vn_edge;     // [N][2]     NtoB: the two edges of a variable node in row order
     const uint8_t *t_last;  // [M*dc]     per (task, edge): 1 when this check node is the LAST visitor of the edge's variable node in a sweep
+    const int *p_dst;       // [n_pairs*2dc] t_dst by (pair, row) for the two-visit kernel
+    const int *p_last;      // [n_pairs*2dc] t_last by (pair, row)
 };
 
 // Device-side frame source (ems_source.hip): the reference's encoder matrices in CSR.

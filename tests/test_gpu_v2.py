@@ -94,25 +94,35 @@ def test_v2_big_code_small_workgroup_shapes(pkg, v2, monkeypatch, waves, occ4):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11)])
 
 
-def test_v2_full_size_batch1024_shapes_agree(pkg, v2):
-    """The bench's batch (1024 frames, four 4-wave workgroups per CU, 128-VGPR build) against the one-frame-per-CU
+@pytest.mark.parametrize("waves", [2, 4, 1])
+def test_v2_big_code_two_visits_per_wave(pkg, v2, monkeypatch, waves):
+    """k_decode_v2_dual (two check nodes per wave; the shape picked from 5 frames per CU on), forced on frames the
+    oracle can follow: decisions, iterations, syndromes and every message array, bit for bit."""
+    monkeypatch.setenv("EMS_DUAL", str(waves))
+    _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11), (0.95, 3)])
+
+
+@pytest.mark.parametrize("B", [1024, 1536])
+def test_v2_full_size_big_batches_shapes_agree(pkg, v2, B):
+    """1024 frames (four 4-wave workgroups per CU, 128-VGPR build of k_decode_v2) and the bench's 1536 (six 2-wave
+    workgroups per CU of k_decode_v2_dual) against the one-frame-per-CU
     launch on 8 distinct frames tiled: decisions, iteration counts, syndromes of every frame and the full state of
     sampled frames agree; one frame is also checked against the oracle."""
     path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
     o = v2.V2Oracle(path)
     base = [v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, sg, seed) for sg, seed in
             ((0.6, 1), (0.7, 2), (0.8, 3), (0.9, 4), (1.0, 5), (0.75, 6), (0.85, 7), (0.95, 8))]
-    like = np.stack([base[i % 8][0] for i in range(1024)])
-    idx = np.stack([base[i % 8][1] for i in range(1024)])
+    like = np.stack([base[i % 8][0] for i in range(B)])
+    idx = np.stack([base[i % 8][1] for i in range(B)])
     code = pkg.Code(path)
-    big = pkg.Decoder(code, 20, 40, 0.3, 9, max_batch=1024)
+    big = pkg.Decoder(code, 20, 40, 0.3, 9, max_batch=B)
     d, it, sy = big.v2_decode_batch(like, idx)
     small = pkg.Decoder(code, 20, 40, 0.3, 9, max_batch=8)
     d8, it8, sy8 = small.v2_decode_batch(like[:8], idx[:8])
     assert len(set(it8.tolist())) > 1                      # frames that stop at different iterations share the CUs
-    for b in range(1024):
+    for b in range(B):
         assert it[b] == it8[b % 8] and sy[b] == sy8[b % 8] and (d[b] == d8[b % 8]).all(), b
-    for b in (0, 5, 517, 1023):
+    for b in (0, 5, 517, B - 1):
         sb, ss = big.v2_state(b), small.v2_state(b % 8)
         for k in STATE:
             assert sb[k].tobytes() == ss[k].tobytes(), (b, k)
