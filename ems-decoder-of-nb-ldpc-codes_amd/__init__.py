@@ -139,6 +139,14 @@ def level_schedule(code):
     return lp[: nl.value + 1].copy(), order
 
 
+def pair_schedule(code):
+    """Pairs of check nodes [(a, b), ...] (b = -1: single) in the order the two-visits-per-wave kernels claim them."""
+    n = C.c_int(0)
+    buf = np.zeros(2 * code.M, np.int32)
+    _check(lib().ems_pair_schedule(C.byref(code.desc), C.byref(n), _ptr(buf)))
+    return buf[: 2 * n.value].reshape(-1, 2).copy()
+
+
 def gf_tables(q):
     """(idx2bin, bin2idx) as LoadTables (init.c:427) derives them from struct.h's binary images."""
     a = np.zeros(q, np.uint8)

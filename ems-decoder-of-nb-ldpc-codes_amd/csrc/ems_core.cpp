@@ -376,6 +376,62 @@ struct Tmp {
 };
 } // namespace
 
+namespace {
+// Task descriptors in level order (t_vn / t_lh / t_pred / t_cnp of the handle) from the level schedule; host only.
+void build_tasks(ems_handle *h, const ems_code_desc *c)
+{
+    const long E = h->E;
+    // per edge the task index of the previous visitor (reference order) of its variable node within the same sweep
+    {
+        std::vector<int> task_of(h->M), last_cn(h->N, -1);
+        for (int i = 0; i < h->M; ++i) task_of[h->lvl_cn[i]] = i;
+        std::vector<int> pred_cn((size_t)E, -1);
+        for (int m = 0; m < h->M; ++m)
+            for (int i = 0; i < h->dc; ++i) {
+                const int v = c->col[m * h->dc + i];
+                pred_cn[(size_t)m * h->dc + i] = last_cn[v];
+                last_cn[v] = m;
+            }
+        h->t_vn.resize(E); h->t_lh.resize(E); h->t_pred.resize(E);
+        for (int i = 0; i < h->M; ++i) {
+            const int m = h->lvl_cn[i];
+            for (int k = 0; k < h->dc; ++k) {
+                const size_t e = (size_t)m * h->dc + k;
+                h->t_vn[(size_t)i * h->dc + k] = c->col[e];
+                h->t_lh[(size_t)i * h->dc + k] = c->coef[e] - 1;
+                h->t_pred[(size_t)i * h->dc + k] = pred_cn[e] < 0 ? -1 : task_of[pred_cn[e]];
+            }
+        }
+        // Static SIMD-arbitration priority of each visit from its slack in the sweep's dependency DAG:
+        // slack = (longest chain) - (longest chain through this task).  Tasks on (or near) a longest chain
+        // gate the sweep; tasks with a lot of slack can yield issue slots to them.  Packed into bits 24..25
+        // of the task's check-node word.
+        {
+            std::vector<int> depth(h->M, 0), height(h->M, 0);
+            for (int i = 0; i < h->M; ++i)
+                for (int k = 0; k < h->dc; ++k) {
+                    const int pr = h->t_pred[(size_t)i * h->dc + k];
+                    if (pr >= 0) depth[i] = std::max(depth[i], depth[pr] + 1);
+                }
+            for (int i = h->M - 1; i >= 0; --i)
+                for (int k = 0; k < h->dc; ++k) {
+                    const int pr = h->t_pred[(size_t)i * h->dc + k];
+                    if (pr >= 0) height[pr] = std::max(height[pr], height[i] + 1);
+                }
+            int cp = 0;
+            for (int i = 0; i < h->M; ++i) cp = std::max(cp, depth[i] + height[i]);
+            h->t_cnp.resize(h->M);
+            for (int i = 0; i < h->M; ++i) {
+                const int slack = cp - (depth[i] + height[i]);
+                const int prio = slack <= 2 ? 3 : (slack <= 8 ? 2 : (slack <= 24 ? 1 : 0));
+                h->t_cnp[i] = h->lvl_cn[i] | (prio << 24);
+            }
+        }
+    }
+
+}
+} // namespace
+
 extern "C" {
 
 const char *ems_last_error(void) { return g_err.c_str(); }
@@ -567,55 +623,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         for (int n = 0; n < h->N; ++n)
             if (!touched[n]) h->iso_vn.push_back(n);
     }
-    // Task descriptors in level order; per edge the task index of the previous visitor (reference order)
-    // of its variable node within the same sweep.
-    {
-        std::vector<int> task_of(h->M), last_cn(h->N, -1);
-        for (int i = 0; i < h->M; ++i) task_of[h->lvl_cn[i]] = i;
-        std::vector<int> pred_cn((size_t)E, -1);
-        for (int m = 0; m < h->M; ++m)
-            for (int i = 0; i < h->dc; ++i) {
-                const int v = c->col[m * h->dc + i];
-                pred_cn[(size_t)m * h->dc + i] = last_cn[v];
-                last_cn[v] = m;
-            }
-        h->t_vn.resize(E); h->t_lh.resize(E); h->t_pred.resize(E);
-        for (int i = 0; i < h->M; ++i) {
-            const int m = h->lvl_cn[i];
-            for (int k = 0; k < h->dc; ++k) {
-                const size_t e = (size_t)m * h->dc + k;
-                h->t_vn[(size_t)i * h->dc + k] = c->col[e];
-                h->t_lh[(size_t)i * h->dc + k] = c->coef[e] - 1;
-                h->t_pred[(size_t)i * h->dc + k] = pred_cn[e] < 0 ? -1 : task_of[pred_cn[e]];
-            }
-        }
-        // Static SIMD-arbitration priority of each visit from its slack in the sweep's dependency DAG:
-        // slack = (longest chain) - (longest chain through this task).  Tasks on (or near) a longest chain
-        // gate the sweep; tasks with a lot of slack can yield issue slots to them.  Packed into bits 24..25
-        // of the task's check-node word.
-        {
-            std::vector<int> depth(h->M, 0), height(h->M, 0);
-            for (int i = 0; i < h->M; ++i)
-                for (int k = 0; k < h->dc; ++k) {
-                    const int pr = h->t_pred[(size_t)i * h->dc + k];
-                    if (pr >= 0) depth[i] = std::max(depth[i], depth[pr] + 1);
-                }
-            for (int i = h->M - 1; i >= 0; --i)
-                for (int k = 0; k < h->dc; ++k) {
-                    const int pr = h->t_pred[(size_t)i * h->dc + k];
-                    if (pr >= 0) height[pr] = std::max(height[pr], height[i] + 1);
-                }
-            int cp = 0;
-            for (int i = 0; i < h->M; ++i) cp = std::max(cp, depth[i] + height[i]);
-            h->t_cnp.resize(h->M);
-            for (int i = 0; i < h->M; ++i) {
-                const int slack = cp - (depth[i] + height[i]);
-                const int prio = slack <= 2 ? 3 : (slack <= 8 ? 2 : (slack <= 24 ? 1 : 0));
-                h->t_cnp[i] = h->lvl_cn[i] | (prio << 24);
-            }
-        }
-    }
-
+    build_tasks(h, c);
     if (h->dc == 4 || h->dc == 8) build_pairs(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
@@ -1109,6 +1117,28 @@ int ems_level_schedule(const ems_code_desc *code, int *n_levels, int *level_ptr,
     if (n_levels) *n_levels = (int)lp.size() - 1;
     if (level_ptr) memcpy(level_ptr, lp.data(), sizeof(int) * lp.size());
     if (order) memcpy(order, lc.data(), sizeof(int) * lc.size());
+    return EMS_OK;
+}
+
+int ems_pair_schedule(const ems_code_desc *code, int *n_pairs, int *pair_cn)
+{
+    if (!code || !code->rowDegree || !code->col || !code->coef || !n_pairs) return fail(EMS_EINVAL, "incomplete code description");
+    ems_handle hh;                                              // host-side fields only; no device is touched
+    hh.N = code->N; hh.M = code->M; hh.E = code->nbBranch; hh.q = code->GF; hh.dc = code->rowDegree[0];
+    for (int m = 0; m < code->M; ++m)
+        if (code->rowDegree[m] != hh.dc) return fail(EMS_EUNSUPPORTED, "irregular check degree");
+    if (hh.dc != 4 && hh.dc != 8) return fail(EMS_EUNSUPPORTED, "pairs are built for check degree 4 and 8 (the two-visits-per-wave kernels)");
+    int r = level_schedule(code, hh.lvl_ptr, hh.lvl_cn);
+    if (r) return r;
+    build_tasks(&hh, code);
+    build_pairs(&hh);
+    *n_pairs = hh.n_pairs;
+    if (pair_cn)
+        for (int i = 0; i < hh.n_pairs; ++i)
+            for (int m = 0; m < 2; ++m) {
+                const int t = hh.p_task[(size_t)i * 2 + m];
+                pair_cn[2 * i + m] = (m == 1 && (hh.p_cn[(size_t)i * 2 + 1] >> 30 & 1)) ? -1 : (hh.t_cnp[t] & 0xFFFFFF);
+            }
     return EMS_OK;
 }
 

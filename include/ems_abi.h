@@ -161,6 +161,12 @@ int ems_get_schedule(ems_handle *h, int *n_levels, int *level_ptr /*[M+1] or NUL
 /* The same schedule computed on the host only (no device needed). */
 int ems_level_schedule(const ems_code_desc *code, int *n_levels, int *level_ptr /*[M+1] or NULL*/, int *order /*[M] or NULL*/);
 
+/* The pairs of check nodes the two-visits-per-wave kernels claim, in claim order, computed on the host only (check degree 4
+ * or 8): pair_cn [2 * n_pairs] (or NULL), second member -1 for a single.  Members of a pair share no variable node and
+ * every earlier visitor (reference order, NB_LDPC.c:320) of their variable nodes sits in an earlier pair, so walking the
+ * pairs in order -- both members at once -- is the sequential sweep exactly. */
+int ems_pair_schedule(const ems_code_desc *code, int *n_pairs, int *pair_cn /*[2*M] or NULL*/);
+
 /* ---- single-node entry points on the device (unit parity of bubble_decoder.c) ---- */
 /* bubble_decoder.c:316 ElementaryStep: index-domain symbols, -1 = invalid, 1e5 = padding value. */
 int ems_elementary_step(int GF, int nm, int nbOper, const float *in1, const float *in2, const int *idx1,

@@ -250,3 +250,28 @@ def test_unit_entry_points_validate_symbol_indices(pkg):
         with pytest.raises(pkg.EmsError) as e:
             pkg.CheckPassLogEMS(np.array([1, 2, 3, 4]), np.zeros((4, 8), np.float32), g, 16, 16, 0.3)
         assert e.value.code == pkg.EMS_EINVAL
+
+
+@pytest.mark.parametrize("name", ["N96_K48_GF64", "Ahmed_64800_R12_GF256", "Ahmed_64800_R34_GF16", "Ahmed_64800_R34_GF256", "Mat24_N192_M96"])
+def test_pair_schedule_properties(pkg, name):
+    """The pairs the two-visits-per-wave kernels claim: every check node exactly once; the members of a pair share no
+    variable node; for every variable node its visitors come in reference order, in different pairs, the earlier pair
+    first -- so visiting the pairs in order, both members at once, is the sequential sweep of NB_LDPC.c:320."""
+    c = pkg.Code(os.path.join(MAT, name))
+    pairs = pkg.pair_schedule(c)
+    cns = pairs[pairs >= 0]
+    assert sorted(cns.tolist()) == list(range(c.M)) and (pairs[:, 0] >= 0).all()
+    col = c.col.reshape(c.M, c.dc)
+    pair_of = np.zeros(c.M, int)
+    for i, (a, b) in enumerate(pairs):
+        pair_of[a] = i
+        if b >= 0:
+            pair_of[b] = i
+            assert not set(col[a]) & set(col[b])
+    last = {}
+    for m in range(c.M):                                    # reference order
+        for v in col[m]:
+            if v in last:
+                assert pair_of[last[v]] < pair_of[m], "variable node %d: check node %d must come in an earlier pair than %d" % (v, last[v], m)
+            last[v] = m
+    assert len(pairs) <= (c.M + 1) // 2 + max(4, c.M // 50)        # nearly everything is paired
