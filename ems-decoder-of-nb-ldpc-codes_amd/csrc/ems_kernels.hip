@@ -1,21 +1,21 @@
 // ems_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels of the EMS NB-LDPC hot path.
 //
 // Mapping (wave64 throughout, no MFMA: this is compare/select/merge work, HBM- and VALU-bound):
-//   * one WORKGROUP per frame, persistent over the whole decode (all sweeps, all levels): frames are
-//     independent, so there is no inter-workgroup communication at all; the only synchronisation is
-//     __syncthreads() between the levels of the layered schedule (NB_LDPC.c:320 order is preserved:
-//     check nodes inside a level share no variable node, levels run in order);
-//   * one WAVEFRONT per check-node visit; the 64 lanes are split into dc "edge rows" of LPE lanes
-//     (LPE = 16 for dc <= 4, 8 for dc <= 8); each row owns one edge: its q-wide APP row is read from
-//     HBM with 16-byte coalesced loads and stays in registers (q/LPE values per lane) from the
-//     variable-node extract (NB_LDPC.c:329-337) to the posterior update (NB_LDPC.c:444-450);
-//   * the L-bubble elementary check node (bubble_decoder.c:316) runs on groups of 8 lanes = its 8
-//     competitors; min-of-8 / winner broadcast are DPP butterflies (quad_perm + row_half_mirror),
-//     the GF(q) addition is an XOR of binary images, the "already in output" set is a 256-bit set
-//     spread over the 8 lanes; up to four elementary steps (forward, backward, two merges) of one
-//     check node run side by side in one wave;
-//   * nm-entry sorted (LLR, symbol) lists, the two q-byte field tables and a q-wide staging row per
-//     edge live in LDS; check-to-variable messages live in HBM in a compact nm*5+5 byte record.
+//   * one WORKGROUP per frame, persistent over the whole decode (all sweeps): frames are independent, so there is no
+//     inter-workgroup communication at all; inside a sweep the check nodes are claimed from an LDS counter in a
+//     topological order of the layered schedule's dependency DAG (NB_LDPC.c:320 order is preserved per variable node)
+//     and a visit waits only for the visits it depends on (done flags in LDS); sweeps are separated by __syncthreads();
+//   * k_decode: one WAVEFRONT per check-node visit; the 64 lanes are split into dc "edge rows" of LPE lanes (LPE = 16 for
+//     dc <= 4, 8 for dc <= 8, 4 beyond); k_decode_dual (the throughput form, BASELINE message sizes): TWO visits per
+//     wavefront, rows of 8 lanes (dc = 4) or 4 lanes (dc = 8).  Each row owns one edge: its q-wide APP row is read from
+//     HBM with 16-byte coalesced loads and stays in registers (q/LPE values per lane) from the variable-node extract
+//     (NB_LDPC.c:329-337) to the posterior update (NB_LDPC.c:444-450);
+//   * the L-bubble elementary check node (bubble_decoder.c:316) runs on groups of 8 lanes = its 8 competitors: a serial
+//     8-way merge (min-of-8 by DPP butterflies; the GF(q) addition is an XOR of binary images) records the picks, a
+//     parallel post-pass applies the stop rules and the "already in output" test (one ds_max per pick on a q-entry LDS
+//     table); up to four (k_decode) or eight (k_decode_dual) elementary steps run side by side in one wave;
+//   * nm-entry sorted (LLR, symbol) lists, the two q-byte field tables and a q-wide staging row per edge live in LDS;
+//     check-to-variable messages live in HBM in a compact nm*5+9 byte record.
 //
 // Bit-exactness: only f32 add/sub/compare on the decode path, compiled with -ffp-contract=off, all
 // tie-breaks (lowest symbol / lowest competitor) and the 1e5 sentinel comparisons as in the reference.
