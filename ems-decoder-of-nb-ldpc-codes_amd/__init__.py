@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("EMS_LIB") or os.path.join(PKG_DIR, "libems_hip.so")  # EMS_LIB: developer override (ablation builds)
 SIM_PATH = os.path.join(PKG_DIR, "ems_sim")
 
-LLR_SUM, LLR_SSD = 0, 1   # ems_abi.h: EMS_LLR_SUM / EMS_LLR_SSD
+LLR_SUM, LLR_SSD, LLR_NEG = 0, 1, 2   # ems_abi.h: EMS_LLR_SUM / EMS_LLR_SSD / EMS_LLR_NEG
 EMS_OK, EMS_EINVAL, EMS_ENODEV, EMS_EHIP, EMS_EIO, EMS_ENOMEM, EMS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -235,6 +235,27 @@ class Decoder:
         assert like.shape == (B, self.code.N, self.code.GF) and like_idx.shape == like.shape
         _check(lib().ems_v2_load_likelihood(self.h, _ptr(like), _ptr(like_idx), B))
         return B
+
+    def v2_channel_likelihood(self, obs, att, table, sigma):
+        """The older generation's channel front end, LLR part (v2.c:1472-1497): obs / att [B][N][2], table [GF][2]."""
+        obs = np.ascontiguousarray(obs, np.float32)
+        att = np.ascontiguousarray(att, np.float32)
+        table = np.ascontiguousarray(table, np.float32)
+        B = obs.shape[0]
+        assert obs.shape == (B, self.code.N, 2) and att.shape == obs.shape and table.shape == (self.code.GF, 2)
+        L = lib()
+        L.ems_v2_channel_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+        _check(L.ems_v2_channel_likelihood(self.h, _ptr(obs), _ptr(att), _ptr(table), np.float32(sigma), B))
+        return B
+
+    def v2_sorted_likelihood(self, frame):
+        """decoder.likelihood / likelihood_index of one frame (v2.c:1483-1497), sorted on the GPU."""
+        like = np.zeros((self.code.N, self.code.GF), np.float32)
+        idx = np.zeros((self.code.N, self.code.GF), np.int32)
+        L = lib()
+        L.ems_v2_get_sorted_likelihood.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _check(L.ems_v2_get_sorted_likelihood(self.h, frame, _ptr(like), _ptr(idx)))
+        return like, idx
 
     def v2_decode(self, B):
         _check(lib().ems_v2_decode(self.h, B))

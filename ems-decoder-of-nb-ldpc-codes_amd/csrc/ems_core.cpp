@@ -200,6 +200,7 @@ struct ems_handle {
     DevBuf<uint8_t> d_v2_vtoci;
     DevBuf<int16_t> d_v2_ctovi;
     bool v2_ready = false;
+    bool v2_from_rows = false;   // the likelihood rows came from ems_v2_channel_likelihood (no sorted staging copy)
     // device-side frame source (allocated by ems_source_attach)
     DevBuf<int> d_src_tptr, d_src_tcol, d_src_rptr, d_src_rcol, d_src_perm;
     DevBuf<uint8_t> d_src_tcoef, d_src_rcoef, d_src_diag, d_src_sym, d_src_rhs;
@@ -690,7 +691,7 @@ int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float
     if (r) return r;
     if (!obs_host || !table_host) return fail(EMS_EINVAL, "null observation or table pointer");
     if (D != 2 && D != 4) return fail(EMS_EINVAL, "constellation dimension %d: 2 or 4", D);
-    if (mode != EMS_LLR_SUM && mode != EMS_LLR_SSD) return fail(EMS_EINVAL, "unknown LLR mode %d", mode);
+    if (mode != EMS_LLR_SUM && mode != EMS_LLR_SSD) return fail(EMS_EINVAL, "unknown LLR mode %d (EMS_LLR_NEG belongs to ems_v2_channel_likelihood)", mode);
     if (mode == EMS_LLR_SUM && D != 2) return fail(EMS_EINVAL, "EMS_LLR_SUM is the two-dimensional form (channel.c:277)");
     if (mode == EMS_LLR_SSD && !att_host) return fail(EMS_EINVAL, "EMS_LLR_SSD needs the per-axis attenuations");
     if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "constellation front ends: GF(64) and GF(256) (the reference's, channel.c:344 / :395)");
@@ -698,15 +699,15 @@ int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float
     if (D > h->logq) return fail(EMS_EINVAL, "D exceeds the staging buffer");
     const size_t n = (size_t)B * h->N * D;
     if (!h->d_ctable.p && (r = h->d_ctable.alloc(256 * 4))) return r;
-    if (mode == EMS_LLR_SSD && h->d_att.n < (size_t)h->max_batch * h->N * 4) {
+    if (att_host && h->d_att.n < (size_t)h->max_batch * h->N * 4) {
         h->d_att.release();
         if ((r = h->d_att.alloc((size_t)h->max_batch * h->N * 4))) return r;
     }
     HIP_TRY(hipMemcpyAsync(h->d_noisy.p, obs_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));   // ([B][N][logGF] staging holds [B][N][D])
-    if (mode == EMS_LLR_SSD) HIP_TRY(hipMemcpyAsync(h->d_att.p, att_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (att_host) HIP_TRY(hipMemcpyAsync(h->d_att.p, att_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_ctable.p, table_host, (size_t)h->q * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    HIP_TRY(ems_launch_llr_const(h->d_noisy.p, mode == EMS_LLR_SSD ? h->d_att.p : nullptr, h->d_ctable.p, h->q, D, mode, sigma, (size_t)B * h->N,
+    HIP_TRY(ems_launch_llr_const(h->d_noisy.p, att_host ? h->d_att.p : nullptr, h->d_ctable.p, h->q, D, mode, sigma, (size_t)B * h->N,
                                  h->d_b2i.p, h->d_app.p, h->stream));
     if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
@@ -1035,6 +1036,59 @@ int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx
     HIP_TRY(hipMemcpyAsync(&bad, h->d_v2_bad.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (bad) return fail(EMS_EINVAL, "v2 flavour: likelihood_index must hold a permutation of 0..GF-1 per node");
+    h->v2_from_rows = false;
+    return EMS_OK;
+}
+
+/* The older generation's channel front end, LLR part (v2.c:1472-1497): likelihood rows from one frame's
+ * observations straight into the decoder's symbol-indexed likelihood block, then the V->C initialisation from them. */
+int ems_v2_channel_likelihood(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, float sigma, int B)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!obs_host || !att_host || !table_host) return fail(EMS_EINVAL, "null observation, attenuation or table pointer");
+    if (h->q != 256 && h->q != 64) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
+    if (!(sigma > 0.f)) return fail(EMS_EINVAL, "sigma must be > 0");
+    if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
+    if ((r = v2_prepare(h))) return r;
+    const size_t n = (size_t)B * h->N * 2;
+    if (!h->d_ctable.p && (r = h->d_ctable.alloc(256 * 4))) return r;
+    if (h->d_att.n < (size_t)h->max_batch * h->N * 4) {
+        h->d_att.release();
+        if ((r = h->d_att.alloc((size_t)h->max_batch * h->N * 4))) return r;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_noisy.p, obs_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_att.p, att_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_ctable.p, table_host, (size_t)h->q * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_v2_bad.p, 0, sizeof(int), h->stream));
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(ems_launch_llr_const(h->d_noisy.p, h->d_att.p, h->d_ctable.p, h->q, 2, EMS_LLR_NEG, sigma, (size_t)B * h->N, h->d_b2i.p, h->d_v2_like.p, h->stream));
+    HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p,
+                                    h->d_v2_bad.p, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_llr_ev = true;
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->d_v2_bad.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad) return fail(EMS_EINVAL, "v2 flavour: a likelihood <= -1e5 among the nm best of a node (the reference would leave index -1 there)");
+    h->v2_from_rows = true;
+    return EMS_OK;
+}
+
+int ems_v2_get_sorted_likelihood(ems_handle *h, int frame, float *like, int *like_idx)
+{
+    int r = check_batch(h, frame + 1);
+    if (r) return r;
+    if (frame < 0 || !h->v2_ready || !like || !like_idx) return fail(EMS_EINVAL, "bad argument");
+    const size_t n = (size_t)h->N * h->q;
+    Tmp t;
+    float *dl = t.up<float>(nullptr, n);
+    int *di = t.up<int>(nullptr, n);
+    if (!dl || !di) return fail(EMS_ENOMEM, "device allocation failed");
+    HIP_TRY(ems_launch_sort_like_desc(h->d_v2_like.p + (size_t)frame * n, h->N, h->q, dl, di, h->stream));
+    HIP_TRY(hipMemcpyAsync(like, dl, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(like_idx, di, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return EMS_OK;
 }
 
@@ -1047,8 +1101,12 @@ int ems_v2_reinit(ems_handle *h, int B)
     if (!h->v2_ready) return fail(EMS_EINVAL, "ems_v2_load_likelihood first");
     if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
-                               h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+    if (h->v2_from_rows)                                       // (the likelihood rows themselves are never modified by a decode)
+        HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_vtoc.p, h->d_v2_vtoci.p,
+                                        h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+    else
+        HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
+                                   h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
     return EMS_OK;

@@ -2135,6 +2135,50 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
     }
 }
 
+// The older generation's initialisation from SYMBOL-INDEXED likelihood rows (what k_llr_const leaves, mode 2): the nm largest of
+// a node in decreasing order, ties -> lowest symbol (= the head of decoder.likelihood / likelihood_index, v2.c:1483-1497) go
+// to both edges of the node as their first V->C messages (v2.c:2101-2113).  One 64-thread block per (frame, node); rank by
+// counting.  A selected value <= -1e5 (the reference would leave index -1 there) is reported through *bad.
+__global__ void k_v2_init_rows(const float *__restrict__ likeS, int N, int q, int nm, int E, const int *__restrict__ vn_edge,
+                               float *__restrict__ vtoc, uint8_t *__restrict__ vtoci, float *__restrict__ hint, int *__restrict__ bad)
+{
+    __shared__ float v[256];
+    const size_t fn = blockIdx.x;
+    const int f = (int)(fn / N), n = (int)(fn % N);
+    for (int g = threadIdx.x; g < q; g += blockDim.x) v[g] = likeS[fn * q + g];
+    __syncthreads();
+    const int e0 = vn_edge[n * 2], e1 = vn_edge[n * 2 + 1];
+    for (int g = threadIdx.x; g < q; g += blockDim.x) {
+        const float vg = v[g];
+        int rank = 0;
+        for (int j = 0; j < q; ++j) rank += (v[j] > vg || (v[j] == vg && j < g)) ? 1 : 0;
+        if (rank < nm) {
+            if (!(vg > -EMS_SENTINEL)) atomicOr(bad, 1);
+            vtoc[((size_t)f * E + e0) * nm + rank] = vg; vtoci[((size_t)f * E + e0) * nm + rank] = (uint8_t)g;
+            vtoc[((size_t)f * E + e1) * nm + rank] = vg; vtoci[((size_t)f * E + e1) * nm + rank] = (uint8_t)g;
+        }
+    }
+    if (threadIdx.x == 0) { hint[(size_t)f * E + e0] = __builtin_inff(); hint[(size_t)f * E + e1] = __builtin_inff(); }
+}
+
+// decoder.likelihood / likelihood_index of one frame (v2.c:1483-1497) from symbol-indexed rows: decreasing (value, symbol)
+// order as a stable rank by counting; values <= -1e5 come out as (-1e5, -1)
+__global__ void k_sort_like_desc(const float *__restrict__ likeS, int q, float *__restrict__ s_like, int *__restrict__ s_idx)
+{
+    __shared__ float v[256];
+    const size_t base = (size_t)blockIdx.x * q;
+    for (int g = threadIdx.x; g < q; g += blockDim.x) v[g] = likeS[base + g];
+    __syncthreads();
+    for (int g = threadIdx.x; g < q; g += blockDim.x) {
+        const float vg = v[g];
+        int rank = 0;
+        for (int j = 0; j < q; ++j) rank += (v[j] > vg || (v[j] == vg && j < g)) ? 1 : 0;
+        const bool ok = vg > -EMS_SENTINEL;
+        s_like[base + rank] = ok ? vg : -EMS_SENTINEL;
+        s_idx[base + rank] = ok ? g : -1;
+    }
+}
+
 // builds the symbol-indexed likelihood rows and the initial V->C messages (v2.c:2101-2113) from the sorted layout
 __global__ void k_v2_init(const float *__restrict__ like, const int *__restrict__ like_idx, int N, int q, int nm, int E,
                           const int *__restrict__ vn_edge, float *__restrict__ likeS, float *__restrict__ vtoc,
@@ -2247,8 +2291,10 @@ __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ nois
 // Channel LLR of the constellation front ends (channel.c:270-283 ModelChannel_AWGN_64, :676-704 ModelChannel,
 // :861-888 ModelChannel_AWGN_256QAM_4D): one GF(q) symbol = one point of a D-dimensional
 // constellation (D = 2 or 4), observed per axis with an attenuation (fading, 0 = erased axis).
-//   mode 0 (SUM): TMP = SQR(y0 - t0)/(2.0*SQR(sigma)) + SQR(y1 - t1)/(2.0*SQR(sigma))   -- both quotients double, one rounding
+//   mode 0 (SUM): TMP = SQR(y0 - t0*a)/(2.0*SQR(sigma)) + SQR(y1 - a*t1)/(2.0*SQR(sigma))   -- both quotients double, one rounding;
+//                 0 for a node with attenuation <= 0 (channel.c:681-684); a = 1 when no attenuations are given (:277)
 //   mode 1 (SSD): TMP = 0; per axis with attenuation > 0: TMP = TMP + SQR(y - a*t)/(2.0*SQR(sigma))   -- float running value
+//   mode 2 (NEG): TMP = -(SQR(..)/(..)) - SQR(..)/(..), the older generation's max-is-best likelihood (v2.c:1479)
 // with the reference's promotions: differences, products and squares in float, quotient and sum in double.
 // One wavefront per (frame, variable node): the table [q][D] (indexed by the symbol's BINARY IMAGE, as the reference's
 // `som`) sits in LDS, lane i evaluates the images i + 64 h, the results pass through a per-wave LDS row (image -> symbol
@@ -2271,15 +2317,17 @@ __global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs
         float y[4], a[4];
         for (int d = 0; d < D; ++d) {
             y[d] = obs[v * D + d];
-            a[d] = (mode == 1) ? att[v * D + d] : 1.0f;
+            a[d] = att ? att[v * D + d] : 1.0f;
         }
         for (int h = 0; h < spl; ++h) {
             const int img = lane + 64 * h;
             const float *t = tab + img * D;
             float tmp;
-            if (mode == 0) {
-                const float e0 = y[0] - t[0], e1 = y[1] - t[1];
-                tmp = (float)((double)(e0 * e0) / den + (double)(e1 * e1) / den);
+            if (mode == 0 || mode == 2) {                       // (a = 1 without attenuations: t * 1.0f is t)
+                const float e0 = y[0] - t[0] * a[0], e1 = y[1] - a[1] * t[1];
+                if (!(a[0] > 0)) tmp = 0.0f;                     // channel.c:681-684 / v2.c:1479-1481
+                else if (mode == 0) tmp = (float)((double)(e0 * e0) / den + (double)(e1 * e1) / den);
+                else tmp = (float)(-((double)(e0 * e0) / den) - (double)(e1 * e1) / den);
             } else {
                 tmp = 0.0f;
                 for (int d = 0; d < D; ++d)
@@ -2688,6 +2736,17 @@ hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int
                               float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st)
 {
     hipLaunchKernelGGL(k_v2_init, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, like, like_idx, N, q, nm, E, vn_edge, likeS, vtoc, vtoci, hint, bad);
+    return hipGetLastError();
+}
+hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, float *vtoc, uint8_t *vtoci,
+                                   float *hint, int *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_v2_init_rows, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, likeS, N, q, nm, E, vn_edge, vtoc, vtoci, hint, bad);
+    return hipGetLastError();
+}
+hipError_t ems_launch_sort_like_desc(const float *likeS, int N, int q, float *s_like, int *s_idx, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sort_like_desc, dim3(N), dim3(64), 0, st, likeS, q, s_like, s_idx);
     return hipGetLastError();
 }
 template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launch_decode_v2_t(const EmsPlan &P, int B, hipStream_t st)

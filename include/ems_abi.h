@@ -83,13 +83,14 @@ int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B);
 /* The constellation front ends of channel.c:112-929 -- LLR part: one GF(q) symbol = one point of a
  * D-dimensional constellation (D = 2: 64-APSK, rotated 64/256-QAM; D = 4: the 4-D 256-QAM), q = 64 or 256.
  *   obs   [B][N][D]  received coordinates (the reference's NoisyBin, channel.c:255-266 / :636-670 / :829-856)
- *   att   [B][N][D]  per-axis attenuation as the LLR sees it (fading, 0 = erased axis); NULL with EMS_LLR_SUM
+ *   att   [B][N][D]  per-axis attenuation as the LLR sees it (fading, 0 = erased axis); may be NULL with EMS_LLR_SUM
+ *                    (no fading); with it, EMS_LLR_SUM gives 0 to a node whose attenuation is <= 0 (channel.c:681-684)
  *   table [q][D]     the normalised constellation, indexed by the symbol's BINARY IMAGE (the reference's `som`)
  *   mode  EMS_LLR_SUM: SQR(y0-t0)/(2 sigma^2) + SQR(y1-t1)/(2 sigma^2), both quotients double, one rounding (channel.c:277)
  *         EMS_LLR_SSD: axes with attenuation > 0 accumulate SQR(y-a*t)/(2 sigma^2) into a float, others are skipped
  *                      (channel.c:690-700, :870-886) -- a node with every axis erased gets an all-zero row
  * The draws (RNG, modulation, fading, erasures) stay on the harness side, as for ems_llr_init. */
-enum { EMS_LLR_SUM = 0, EMS_LLR_SSD = 1 };
+enum { EMS_LLR_SUM = 0, EMS_LLR_SSD = 1, EMS_LLR_NEG = 2 /* the v2 flavour's max-is-best form, see ems_v2_channel_likelihood */ };
 int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, int D, int mode,
                                float sigma, int B);
 /* Alternative input for tests: load APP directly from [B][N][GF] LLRs indexed by symbol. */
@@ -148,6 +149,14 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
  *   Results through ems_get_results (decide, iterations executed, syndrome). */
 int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx, int B);
 int ems_v2_decode(ems_handle *h, int B);
+/* The older generation's own channel front end, LLR part (ModelChannelAWGN, v2.c:1472-1497) instead of
+ * ems_v2_load_likelihood: obs [B][N][2] received coordinates, att [B][N][2] the node's fading on both axes (ATT[n]),
+ * table [GF][2] the scaled constellation by binary image (TABLEAU), sigma (v2.c:1451).  The likelihoods
+ * -(SQR(y0-t0*A)/(2 sigma^2)) - SQR(y1-A*t1)/(2 sigma^2) (0 where A <= 0) go straight into the decoder's symbol-indexed block
+ * and the V->C messages start from each node's nm best (v2.c:2101-2113); ems_v2_get_sorted_likelihood returns what the
+ * reference keeps as decoder.likelihood / likelihood_index ([N][GF] each, decreasing) for one frame. */
+int ems_v2_channel_likelihood(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, float sigma, int B);
+int ems_v2_get_sorted_likelihood(ems_handle *h, int frame, float *like, int *like_idx);
 /* initialisation again from the likelihoods already staged in HBM by the last ems_v2_load_likelihood (timed with
  * ems_last_llr_ms): lets a harness repeat a decode without the host upload */
 int ems_v2_reinit(ems_handle *h, int B);

@@ -94,9 +94,12 @@ void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const
 }
 
 /* The LLR rows (what the GPU kernel computes).  table [q][D] indexed by binary image; llr [N][q] indexed by symbol.
- * mode 0 (SUM, channel.c:277): D = 2, both quotients added in double, one rounding to float; att is not used.
+ * mode 0 (SUM, channel.c:277; with fading :681-684): D = 2, both quotients added in double, one rounding to float; with
+ *         attenuations (att != NULL; the same on both axes in the reference) a node with attenuation <= 0 gets 0.
  * mode 1 (SSD, channel.c:690-700 / :870-886): axes with attenuation <= 0 are skipped, each quotient is added to the
- *         float running value in double and rounded back (the first assignment equals an addition to 0). */
+ *         float running value in double and rounded back (the first assignment equals an addition to 0).
+ * mode 2 (NEG, the older generation's max-is-best likelihood, EMS_HS_L-BubbleCheck_UBS_decoder_v2.c:1479):
+ *         -(q0) - q1 in double, one rounding; 0 when the attenuation is <= 0. */
 void orc_const_llr(const orc_gf *gf, const float *table, int q, int D, int mode, const float *obs, const float *att, int N,
                    float sigma, float *llr)
 {
@@ -106,9 +109,12 @@ void orc_const_llr(const orc_gf *gf, const float *table, int q, int D, int mode,
             const float *t = table + (size_t)gf->idx2bin[k] * D;
             const float *y = obs + (size_t)n * D;
             float tmp;
-            if (mode == 0) {
-                const float a0 = y[0] - t[0], a1 = y[1] - t[1];
-                tmp = (float)((double)(a0 * a0) / den + (double)(a1 * a1) / den);
+            if (mode == 0 || mode == 2) {
+                const float f0 = att ? att[(size_t)n * D + 0] : 1.0f, f1 = att ? att[(size_t)n * D + 1] : 1.0f;
+                const float a0 = y[0] - t[0] * f0, a1 = y[1] - f1 * t[1];
+                if (!(f0 > 0)) tmp = 0.0f;
+                else if (mode == 0) tmp = (float)((double)(a0 * a0) / den + (double)(a1 * a1) / den);
+                else tmp = (float)(-((double)(a0 * a0) / den) - (double)(a1 * a1) / den);
             } else {
                 tmp = 0.0f;
                 for (int d = 0; d < D; d++) {
@@ -121,4 +127,53 @@ void orc_const_llr(const orc_gf *gf, const float *table, int q, int D, int mode,
             }
             llr[(size_t)n * q + k] = tmp;
         }
+}
+
+/* ---- the older generation's channel front end (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c:1167-1499) ---- */
+
+/* v2.c:1184-1446: TABLEAU is the 16 x 16 grid (-7.5 + i/16, -7.5 + i%16), i = the symbol's binary image, scaled by
+ * float R = 0.433860915637 (pinned through the likelihoods of all 256 symbols against the real function) */
+void orc_v2_table(float *out /*[256][2]*/)
+{
+    const float R = (float)0.433860915637;
+    for (int i = 0; i < 256; i++) {
+        out[2 * i + 0] = R * (-7.5f + (float)(i / 16));
+        out[2 * i + 1] = R * (-7.5f + (float)(i % 16));
+    }
+}
+
+/* v2.c:1451-1470: per node one fading draw w, A = sqrt(-log(w)), then per axis u, v (drand48 straight into floats);
+ * obs = point*A + noise, att = A on both axes.  sigma as orc_chan_sigma (v2.c:1451). */
+void orc_v2_chan_draw(orc_rng *r, const float *table, int N, const int *images, float sigma, float *obs, float *att)
+{
+    for (int n = 0; n < N; n++) {
+        const float w = my_drand48f(r);
+        const float A = (float)sqrt(-log((double)w));
+        for (int d = 0; d < 2; d++) {
+            const float u = my_drand48f(r);
+            const float v = my_drand48f(r);
+            obs[2 * n + d] = (float)((double)(table[2 * images[n] + d] * A) + (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * CH_PI * (double)v));
+            att[2 * n + d] = A;
+        }
+    }
+}
+
+/* v2.c:1483-1497: q rounds of "first strict maximum above -1e5, then mark it -1e5": the likelihoods in decreasing
+ * order with their symbols (decoder.likelihood / likelihood_index) */
+void orc_v2_sort_likelihood(const float *like, int N, int q, float *s_like, int *s_idx)
+{
+    float *tmp = malloc(sizeof(float) * (size_t)q);
+    for (int n = 0; n < N; n++) {
+        memcpy(tmp, like + (size_t)n * q, sizeof(float) * (size_t)q);
+        for (int k = 0; k < q; k++) {
+            float best = -1e5f;
+            int bg = -1;
+            for (int g = 0; g < q; g++)
+                if (tmp[g] > best) { best = tmp[g]; bg = g; }
+            s_like[(size_t)n * q + k] = best;
+            s_idx[(size_t)n * q + k] = bg;
+            if (bg >= 0) tmp[bg] = -1e5f;
+        }
+    }
+    free(tmp);
 }

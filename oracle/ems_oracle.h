@@ -118,5 +118,9 @@ void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const
                    float *obs /*[N][D]*/, float *att /*[N][D]*/);
 void orc_const_llr(const orc_gf *gf, const float *table, int q, int D, int mode, const float *obs, const float *att, int N,
                    float sigma, float *llr /*[N][q]*/);
+/* the older generation's own channel (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c:1167-1499): grid table, draws, decreasing sort */
+void orc_v2_table(float *out /*[256][2]*/);
+void orc_v2_chan_draw(orc_rng *r, const float *table, int N, const int *images, float sigma, float *obs, float *att);
+void orc_v2_sort_likelihood(const float *like, int N, int q, float *s_like, int *s_idx);
 
 #endif

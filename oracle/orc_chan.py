@@ -12,7 +12,7 @@ import numpy as np
 import orc
 
 KINDS = {"apsk64": 0, "qamr_ssd": 1, "qam4d": 2}     # ModelChannel_AWGN_64 / ModelChannel / ModelChannel_AWGN_256QAM_4D
-MODE_SUM, MODE_SSD = 0, 1
+MODE_SUM, MODE_SSD, MODE_NEG = 0, 1, 2
 
 
 def _f(a): return a.ctypes.data_as(C.POINTER(C.c_float))
@@ -49,9 +49,15 @@ class Channel:
             assert q == 256
             self.D, self.mode = 4, MODE_SSD
             t = np.ascontiguousarray(raw["qam256_4d_16qam_r"], np.float32).copy()
+        elif kind == "v2grid":                           # the older generation's ModelChannelAWGN (v2.c:1167): no normalisation pass
+            assert q == 256
+            self.D, self.mode = 2, MODE_NEG
+            t = np.zeros((256, 2), np.float32)
+            L.orc_v2_table(_f(t))
         else:
             raise ValueError(kind)
-        L.orc_const_normalise(_f(t), q, self.D)
+        if kind != "v2grid":
+            L.orc_const_normalise(_f(t), q, self.D)
         self.table = t                                   # [q][D], indexed by the symbol's binary image
 
     def sigma(self, EbN):
@@ -63,13 +69,24 @@ class Channel:
         images = self.idx2bin[np.asarray(codeword)].astype(np.int32)
         obs = np.zeros((N, self.D), np.float32)
         att = np.zeros((N, self.D), np.float32)
+        if self.kind == "v2grid":
+            lib().orc_v2_chan_draw(C.byref(rng), _f(self.table), N, _i(images), C.c_float(sigma), _f(obs), _f(att))
+            return obs, att
         lib().orc_chan_draw(C.byref(rng), KINDS[self.kind], _f(self.table), self.D, N, _i(images), C.c_float(sigma), _f(obs), _f(att))
         return obs, att
 
-    def llr(self, obs, att, sigma):
+    def llr(self, obs, att, sigma, mode=None):
         N = obs.shape[0]
         out = np.zeros((N, self.q), np.float32)
         obs = np.ascontiguousarray(obs, np.float32)
-        att = np.ascontiguousarray(att, np.float32)
-        lib().orc_const_llr(C.byref(self.gf), _f(self.table), self.q, self.D, self.mode, _f(obs), _f(att), N, C.c_float(sigma), _f(out))
+        att = None if att is None else np.ascontiguousarray(att, np.float32)
+        lib().orc_const_llr(C.byref(self.gf), _f(self.table), self.q, self.D, self.mode if mode is None else mode, _f(obs),
+                            _f(att) if att is not None else None, N, C.c_float(sigma), _f(out))
         return out
+
+    def sort_likelihood(self, like):
+        """Decreasing order with symbols (decoder.likelihood / likelihood_index of the older generation, v2.c:1483-1497)."""
+        N = like.shape[0]
+        sl, si = np.zeros((N, self.q), np.float32), np.zeros((N, self.q), np.int32)
+        lib().orc_v2_sort_likelihood(_f(np.ascontiguousarray(like, np.float32)), N, self.q, _f(sl), _i(si))
+        return sl, si

@@ -105,4 +105,16 @@ if __name__ == "__main__":
         out[tag + "_gf_head"] = sg[:head].astype(np.int16)
         out[tag + "_crc"] = np.array([orc.crc32(sl), orc.crc32(sg.astype(np.int32))], np.uint32)
         print(tag, sl.shape, "crc", out[tag + "_crc"])
+    # the older generation's own channel (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c:1167) on the all-zero codeword, srand48(5),
+    # through the hook of oracle/ref_v2_shim.c: decoder.likelihood / likelihood_index
+    import orc_v2
+    r = orc_v2.RefV2(os.path.join(MAT, "Ahmed_64800_R12_GF256"), 20)
+    like, idx = r.channel_zero_codeword(11.0, 5)
+    r.close()
+    out["v2chan_ebn"] = np.float32(11.0)
+    out["v2chan_seed"] = np.int32(5)
+    out["v2chan_like_head"] = like[:16]
+    out["v2chan_idx_head"] = idx[:16].astype(np.int16)
+    out["v2chan_crc"] = np.array([orc.crc32(like), orc.crc32(idx.astype(np.int32))], np.uint32)
+    print("v2chan", like.shape, out["v2chan_crc"])
     np.savez_compressed(os.path.join(HERE, "channel_const.npz"), **out)

@@ -77,3 +77,51 @@ def test_oracle_channels_vs_live_reference(orc, chan, tag, kind, fn, matrix):
         obs, att = ch.draw(orc.Rng(0), cw, sigma)
         s2, g2 = o.sort_llr(ch.llr(obs, att, sigma))
         assert s2.tobytes() == sl.tobytes() and (g2 == sg).all()
+
+
+def test_older_generation_channel_reproduces_reference_output(orc, chan):
+    """ModelChannelAWGN of EMS_HS_L-BubbleCheck_UBS_decoder_v2.c (:1167-1499; grid constellation, one fading draw per
+    node, max-is-best likelihoods, decreasing sort) on the all-zero codeword with srand48(5): the oracle's draws + mode-2
+    LLR + sort against decoder.likelihood / likelihood_index of the real function (fixture; live where oracle/_ref is built)."""
+    raw = gold("channel_const.npz")
+    ch = chan.Channel("v2grid", 256, None)
+    ebn, seed = float(raw["v2chan_ebn"]), int(raw["v2chan_seed"])
+    sigma = ch.sigma(ebn)
+    N = 8100
+    obs, att = ch.draw(orc.Rng((seed << 16) | 0x330E), np.zeros(N, np.int32), sigma)          # srand48(seed)
+    like = ch.llr(obs, att, sigma)
+    assert (like <= 0).all()
+    sl, si = ch.sort_likelihood(like)
+    assert sl[:16].tobytes() == raw["v2chan_like_head"].tobytes() and (si[:16] == raw["v2chan_idx_head"]).all()
+    assert orc.crc32(sl) == int(raw["v2chan_crc"][0]) and orc.crc32(si) == int(raw["v2chan_crc"][1])
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    v2 = importlib.import_module("orc_v2")
+    if os.path.exists(v2.REF_V2):
+        r = v2.RefV2(os.path.join(MAT, "Ahmed_64800_R12_GF256"), 20)
+        for ebn2, seed2 in ((7.0, 9), (15.0, 10)):
+            like_r, idx_r = r.channel_zero_codeword(ebn2, seed2)
+            s2 = ch.sigma(ebn2)
+            o2, a2 = ch.draw(orc.Rng((seed2 << 16) | 0x330E), np.zeros(N, np.int32), s2)
+            l2, i2 = ch.sort_likelihood(ch.llr(o2, a2, s2))
+            assert l2.tobytes() == like_r.tobytes() and (i2 == idx_r).all()
+        r.close()
+
+
+def test_sum_mode_with_fading(orc, chan):
+    """EMS_LLR_SUM with attenuations (the `rayleigh_fading` form of channel.c:681-684): one rounding of the double sum,
+    0 for a node whose attenuation is <= 0; mode 2 is its negation except for the sign of an exact zero."""
+    raw = gold("channel_const.npz")
+    ch = chan.Channel("qamr_ssd", 64, raw)
+    rs = np.random.RandomState(4)
+    obs = rs.randn(50, 2).astype(np.float32)
+    a = np.abs(rs.randn(50)).astype(np.float32)
+    a[::7] = 0.0
+    att = np.stack([a, a], 1)
+    s0 = ch.llr(obs, att, 0.4, mode=chan.MODE_SUM)
+    s2 = ch.llr(obs, att, 0.4, mode=chan.MODE_NEG)
+    assert (s0[::7] == 0).all() and (s0[1] > 0).all()
+    assert (s2 == -s0).all()
+    t = ch.table[ch.idx2bin]
+    e0 = (obs[1, 0] - t[:, 0] * a[1]).astype(np.float32); e1 = (obs[1, 1] - a[1] * t[:, 1]).astype(np.float32)
+    den = 2.0 * float(np.float32(0.4) * np.float32(0.4))
+    assert s0[1].tobytes() == ((e0 * e0).astype(np.float64) / den + (e1 * e1).astype(np.float64) / den).astype(np.float32).tobytes()

@@ -141,3 +141,72 @@ def test_front_end_argument_checks(pkg):
         d16.llr_init_constellation(np.zeros((1, d16.code.N, 2), np.float32), None, np.zeros((16, 2), np.float32), pkg.LLR_SUM, 0.3)
     assert e.value.code == pkg.EMS_EUNSUPPORTED
     d16.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the older generation's own channel front end (EMS_HS_L-BubbleCheck_UBS_decoder_v2.c:1167-1499)
+# ---------------------------------------------------------------------------------------------------
+def test_older_generation_channel_front_end(pkg, orc, chan):
+    """ems_v2_channel_likelihood against the real ModelChannelAWGN (fixture: zero codeword, srand48(5)) and, for random
+    codewords, against the oracle; then a whole decode started from it must equal the decode started from the sorted
+    likelihood arrays (ems_v2_load_likelihood) and the v2 oracle's, every message array included."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    v2 = importlib.import_module("orc_v2")
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
+    ch = chan.Channel("v2grid", 256, None)
+    o = v2.V2Oracle(path)
+    N = o.N
+    ebn, seed = float(raw["v2chan_ebn"]), int(raw["v2chan_seed"])
+    sigma = ch.sigma(ebn)
+    obs0, att0 = ch.draw(orc.Rng((seed << 16) | 0x330E), np.zeros(N, np.int32), sigma)
+    rs = np.random.RandomState(8)
+    cw1 = rs.randint(0, 256, N).astype(np.int32)                # not a codeword: the front end does not care
+    s1 = ch.sigma(14.0)
+    obs1, att1 = ch.draw(orc.Rng(77), cw1, s1)
+    att1[5] = 0.0                                               # a node the fading wiped out: all-zero likelihood row
+    code = pkg.Code(path)
+    dec = pkg.Decoder(code, 20, 40, 0.3, 8, max_batch=2)
+    # frame by frame (each has its own sigma)
+    for b, (ob, at, sg) in enumerate(((obs0, att0, sigma), (obs1, att1, s1))):
+        dec.v2_channel_likelihood(ob[None], at[None], ch.table, sg)
+        like, idx = dec.v2_sorted_likelihood(0)
+        ol, oi = ch.sort_likelihood(ch.llr(ob, at, sg))
+        assert like.tobytes() == ol.tobytes() and (idx == oi).all()
+        if b == 0:
+            assert like[:16].tobytes() == raw["v2chan_like_head"].tobytes() and (idx[:16] == raw["v2chan_idx_head"]).all()
+            assert orc.crc32(like) == int(raw["v2chan_crc"][0]) and orc.crc32(idx) == int(raw["v2chan_crc"][1])
+        else:
+            assert (like[5] == 0).all()
+        dec.v2_decode(1)
+        d, it, sy = dec.results(1)
+        st = dec.v2_state(0)
+        ref = o.decode(ol, oi, 20, 40, 0.3, 8)
+        assert it[0] == ref["iters"] and sy[0] == ref["synd"] and (d[0] == ref["decide"]).all()
+        for k in ("vtoc", "vtoci", "ctov", "ctovi", "app"):
+            assert st[k].tobytes() == ref[k].tobytes(), k
+        d2, it2, sy2 = dec.v2_decode_batch(ol[None], oi[None])   # the same frame through the sorted-array input
+        assert it2[0] == it[0] and sy2[0] == sy[0] and (d2[0] == d[0]).all()
+        dec.v2_channel_likelihood(ob[None], at[None], ch.table, sg)
+        dec.v2_decode(1); dec.v2_reinit(1); dec.v2_decode(1)     # reinit re-runs the initialisation from the rows
+        d3, it3, sy3 = dec.results(1)
+        assert it3[0] == it[0] and (d3[0] == d[0]).all()
+    dec.close()
+
+
+def test_sum_mode_with_fading_on_gpu(pkg, orc, chan):
+    """EMS_LLR_SUM with attenuations (channel.c:681-684 form) against the oracle, erased nodes included."""
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, "N96_K48_GF64")
+    ch = chan.Channel("qamr_ssd", 64, raw)
+    rs = np.random.RandomState(12)
+    obs = rs.randn(3, 16, 2).astype(np.float32)
+    a = np.abs(rs.randn(3, 16)).astype(np.float32)
+    a[:, ::5] = 0.0
+    att = np.stack([a, a], 2)
+    dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 4, max_batch=3)
+    dec.llr_init_constellation(obs, att, ch.table, pkg.LLR_SUM, 0.4)
+    dec.synchronize()
+    for b in range(3):
+        assert dec.app(b).tobytes() == ch.llr(obs[b], att[b], 0.4, mode=chan.MODE_SUM).tobytes()
+    dec.close()
