@@ -452,6 +452,26 @@ def test_decode_n96_two_visits_per_wave_vs_oracle(pkg, orc, monkeypatch):
         _decode_vs_oracle(pkg, orc, "KN_N96_K48_GF64.txt", 16, 32, 0.3, 30, -3.0, 8, state=True, early_exit=False)
 
 
+def test_two_visit_kernels_random_parameter_sweep(pkg, orc, monkeypatch):
+    """Seeded random (NbOper, offset, NbIterMax, Eb/N0, early exit, workgroup shape) through the two-visits-per-wave builds on
+    small codes of their three families -- GF(256) dc 4 nm 20, GF(64) dc 4 nm 16, and (one frame of the long code) GF(16) dc 8
+    nm 8: whole-frame state against the oracle each time.  NbOper from nm+3 (first pass only) to 64 (long continuations),
+    low SNR for short outputs and ties, codes with single (unpaired) check nodes."""
+    rs = np.random.RandomState(77)
+    fam = [("KN_N128_K64_GF256.txt", 20), ("Mat24_N192_M96", 16), ("N96_K48_GF64", 16), ("KN_N96_K48_GF64.txt", 16)]
+    for trial in range(24):
+        name, nm = fam[trial % len(fam)]
+        nop = int(rs.choice([nm + 3, nm + 4, nm + 8, 2 * nm, 3 * nm, 64]))
+        off = float(rs.choice([0.0, 0.3, 0.7, 1.0]))
+        itmax = int(rs.randint(2, 13))
+        ebn = float(rs.choice([-2.0, 0.5, 2.0, 3.5, 6.0]))
+        monkeypatch.setenv("EMS_DUAL", str(int(rs.choice([1, 2, 4]))))
+        _decode_vs_oracle(pkg, orc, name, nm, nop, off, itmax, ebn, 5, state=True, early_exit=bool(trial % 3))
+    for nop, off, itmax, ebn, ee in ((11, 0.3, 5, 1.0, False), (16, 0.0, 7, 2.6, True), (40, 1.0, 4, 0.0, False)):
+        monkeypatch.setenv("EMS_DUAL", "4")
+        _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, nop, off, itmax, ebn, 1, state=True, early_exit=ee)
+
+
 def test_full_size_n96_batch8192(pkg, orc):
     path = os.path.join(MAT, "N96_K48_GF64")
     o = orc.Oracle(path)

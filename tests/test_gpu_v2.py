@@ -67,6 +67,19 @@ def test_v2_random_parameter_sweep(pkg, v2):
         _check_frames(pkg, v2, name, q, lq, nm, nop, off, itmax, cases, early_exit=bool(trial % 3))
 
 
+def test_v2_two_visit_kernel_parameter_sweep(pkg, v2, monkeypatch):
+    """Seeded random (NbOper 23..64, offset, NbIterMax, noise, early exit, workgroup shape) through k_decode_v2_dual on the
+    small GF(256) dc = 4 code (8 check nodes: pairs and singles), every message array against the oracle."""
+    rs = np.random.RandomState(99)
+    for trial in range(12):
+        nop = int(rs.choice([23, 24, 30, 40, 60, 64]))
+        off = float(rs.choice([0.0, 0.3, 0.5, 1.0]))
+        itmax = int(rs.randint(2, 10))
+        cases = [(float(rs.choice([0.5, 0.7, 0.9, 1.2])), int(rs.randint(1, 10 ** 6))) for _ in range(3)]
+        monkeypatch.setenv("EMS_DUAL", str(int(rs.choice([1, 2, 4]))))
+        _check_frames(pkg, v2, "KN_N128_K64_GF256.txt", 256, 8, 20, nop, off, itmax, cases, early_exit=bool(trial % 3))
+
+
 def test_v2_check_degree_8(pkg, v2):
     """dc = 8 (rows of 8 lanes): GF(256) rate 3/4 (UBS and full-alist files), GF(64) small code."""
     _check_frames(pkg, v2, "Ahmed_64800_R34_GF256", 256, 8, 20, 40, 0.3, 6, [(0.5, 21), (0.62, 22)])
