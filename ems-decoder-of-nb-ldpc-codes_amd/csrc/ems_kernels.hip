@@ -2582,7 +2582,7 @@ static bool spec_ok(const EmsPlan &P) { return P.nbOper >= P.nm + 3 && P.nbOper 
 bool ems_has_dual_kernel(const EmsPlan &P)
 {
     return spec_ok(P) && P.n_pairs > 0 &&
-           ((P.q == 256 && P.dc == 4 && P.nm == 20) || (P.q == 16 && P.dc == 8 && P.nm == 8) || (P.q == 64 && P.dc == 4 && P.nm == 16));
+           ((P.q == 256 && P.dc == 4 && P.nm == 20) || (P.q == 16 && P.dc == 8 && P.nm == 8) || (P.q == 64 && P.dc == 4 && (P.nm == 16 || P.nm == 24)));   // (nm = 24: the reference's own test description, NB_LDPC.c:48-60)
 }
 int ems_dual_max_waves(int dc) { return dc == 4 ? 4 : 16; }
 size_t ems_dual_wave_lds_bytes(int q, int dc, int nm) { return (size_t)dual_wave_bytes(q, dc, nm); }
@@ -2607,7 +2607,7 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
         if (!ems_has_dual_kernel(P) || P.waves_per_wg > ems_dual_max_waves(P.dc) || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.dc, P.nm))
             return hipErrorInvalidValue;
         if (P.dc == 4 && P.q == 256) return launch_decode_dual_t<256, 20, 4>(P, B, st);
-        if (P.dc == 4) return launch_decode_dual_t<64, 16, 4>(P, B, st);
+        if (P.dc == 4) return P.nm == 16 ? launch_decode_dual_t<64, 16, 4>(P, B, st) : launch_decode_dual_t<64, 24, 4>(P, B, st);
         return launch_decode_dual_t<16, 8, 8>(P, B, st);
     }
     if (P.occ4 && P.waves_per_wg <= 4 && ems_has_occ4_kernel(P)) return launch_decode_t<256, 16, 4, 20, true>(P, B, st);

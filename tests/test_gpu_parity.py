@@ -458,10 +458,10 @@ def test_two_visit_kernels_random_parameter_sweep(pkg, orc, monkeypatch):
     nm 8: whole-frame state against the oracle each time.  NbOper from nm+3 (first pass only) to 64 (long continuations),
     low SNR for short outputs and ties, codes with single (unpaired) check nodes."""
     rs = np.random.RandomState(77)
-    fam = [("KN_N128_K64_GF256.txt", 20), ("Mat24_N192_M96", 16), ("N96_K48_GF64", 16), ("KN_N96_K48_GF64.txt", 16)]
-    for trial in range(24):
+    fam = [("KN_N128_K64_GF256.txt", 20), ("Mat24_N192_M96", 16), ("N96_K48_GF64", 16), ("KN_N96_K48_GF64.txt", 16), ("Mat24_N192_M96", 24)]
+    for trial in range(30):
         name, nm = fam[trial % len(fam)]
-        nop = int(rs.choice([nm + 3, nm + 4, nm + 8, 2 * nm, 3 * nm, 64]))
+        nop = min(64, int(rs.choice([nm + 3, nm + 4, nm + 8, 2 * nm, 3 * nm, 64])))
         off = float(rs.choice([0.0, 0.3, 0.7, 1.0]))
         itmax = int(rs.randint(2, 13))
         ebn = float(rs.choice([-2.0, 0.5, 2.0, 3.5, 6.0]))
