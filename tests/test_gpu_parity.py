@@ -195,6 +195,30 @@ def test_isolated_variable_node_is_decided_from_its_channel_llr(pkg, orc, tmp_pa
     dec.close()
 
 
+def test_set_params_switches_kernels_and_keeps_the_record_layout(pkg, orc, monkeypatch):
+    """ems_set_params after ems_create: lowering nm (and NbOper, offset) takes the handle off the nm = 20 two-visit build onto
+    the generic kernel; records stay strided by the create-time nm while their fields follow the current one, so APP, the
+    expanded C->V rows (ems_get_ctov) and the decisions must still equal the oracle's; raising nm back returns to the
+    two-visit build."""
+    monkeypatch.setenv("EMS_DUAL", "2")
+    path = os.path.join(MAT, "KN_N128_K64_GF256.txt")
+    o = orc.Oracle(path)
+    sigma = o.sigma(2.5)
+    rng = orc.Rng(0)
+    noisy = np.stack([o.draw_frame(rng, sigma)[1] for _ in range(6)])
+    dec = pkg.Decoder(pkg.Code(path), 20, 40, 0.3, 8, max_batch=6)
+    for nm, nop, off in ((20, 40, 0.3), (12, 20, 0.5), (20, 64, 0.0), (5, 9, 1.0), (20, 23, 0.3)):
+        dec.set_params(nm=nm, nbOper=nop, offset=off)
+        d, it, sy = dec.decode_batch(noisy, sigma)
+        for b in range(6):
+            ref = o.decode(o.llr(noisy[b], sigma), nm, nop, off, 8, want_state=True)
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], (nm, b)
+            assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), (nm, b)
+    with pytest.raises(pkg.EmsError):
+        dec.set_params(nm=24)                                   # above the create-time value
+    dec.close()
+
+
 def test_unsupported_configurations_fail_loudly(pkg):
     code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
     with pytest.raises(pkg.EmsError) as e:
