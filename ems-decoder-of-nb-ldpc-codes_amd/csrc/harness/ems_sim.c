@@ -5,7 +5,7 @@
  * frame, never reseeded), same progress line, same 40-erroneous-frame stop and same result-file line as
  * the reference's main() (NB_LDPC.c:63-604).  The only structural change is the one north_star asks
  * for: the inline per-frame decode block (NB_LDPC.c:266-472) is replaced by one batched call into the
- * GPU library -- frames are generated EMS_BATCH at a time (default 64, env EMS_BATCH) by EMS_THREADS host
+ * GPU library -- frames are generated EMS_BATCH at a time (default 1536, env EMS_BATCH) by EMS_THREADS host
  * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
  * Several decoder handles (EMS_INFLIGHT, default 3) take turns so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
@@ -89,7 +89,9 @@ int main(int argc, char *argv[])
     const int nbMax = atoi(argv[5]);
     const float offset = (float)atof(argv[6]);
     const int NbOper = atoi(argv[7]);
-    int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 64;
+    /* default batch: 1536 frames = 6 per CU of an MI355X, the shape that runs the two-visits-per-wave kernel */
+    int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 1536;
+    if (batch > NbMonteCarlo) batch = NbMonteCarlo;            /* (no buffers for frames that are never drawn) */
     if (batch < 1) batch = 1;
     const int device = getenv("EMS_DEVICE") ? atoi(getenv("EMS_DEVICE")) : 0;
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
