@@ -901,7 +901,9 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
                                                  float *drow, int sw = 0)   // sw: index swizzle of the staging row (dual_row_swz), else 0
 {
     using G = Geo<Q, LPE>;
-    constexpr int SPL = SEL_CAP / LPE; // survivors ranked per lane
+    constexpr int CAPQ = Q < SEL_CAP ? Q : SEL_CAP;   // survivor slots that can hold something (a field of 16 never fills 32)
+    constexpr int SPL = CAPQ / LPE;                    // survivors ranked per lane
+    static_assert(SPL >= 1 && SPL * LPE == CAPQ, "rows of LPE lanes must tile the survivor slots");
     // wide rows: the survivors of a threshold are kept as a per-lane bit mask (above_mask) and compacted by walking
     // the set bits -- a lane owns EPL symbols but only one or two survive
     constexpr bool BYMASK = (G::EPL >= 4) && (G::EPL <= 32) && (Q > SEL_CAP);   // (the mask is one 32-bit word)
@@ -1012,7 +1014,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         }
     }
 #pragma unroll
-    for (int k = 0; k < SPL; ++k) {                                     // slots cnt..SEL_CAP-1 never count as smaller
+    for (int k = 0; k < SPL; ++k) {                                     // slots cnt..CAPQ-1 never count as smaller
         const int idx = rl + k * LPE;
         svals[idx >= cnt ? idx : SEL_CAP + rl] = __builtin_inff();
     }
