@@ -348,7 +348,7 @@ int refresh_plan(ems_handle *h)
     P.wave_lds_bytes = (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
     int widest = 1;
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-    const int wcap = ems_max_waves_for(h->dc);
+    const int wcap = ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
     if (const char *ew = getenv("EMS_WAVES")) waves = std::max(1, std::min(wcap, atoi(ew)));   // developer knob
     const size_t lds_cap = 160 * 1024;
@@ -754,7 +754,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     // a code whose levels hold a handful of check nodes (the N = 96 bits GF(64) code: 8 check nodes, levels of 1-3) keeps a workgroup of
     // one wave busy at best: one wave walking the pairs in order, two visits at a time (measured 1.72e6 against 1.42e6 frames/s)
     if (allow_dual && !(ed && atoi(ed) == 0) && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu && ems_has_dual_kernel(P)) { go_dual(1); return; }
-    if (ems_max_waves_for(h->dc) != 12 || P.waves_per_wg < 12 || h->n_cu <= 0) return;
+    if (ems_lpe_for(h->dc) != 16 || P.waves_per_wg < 12 || h->n_cu <= 0) return;   // (the batch shapes below belong to the dc <= 4 kernels)
     const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU

@@ -7,7 +7,7 @@
 #include "ems_plan.h"
 
 int ems_lpe_for(int dc);                                     // lanes per edge row; 0 = unsupported degree
-int ems_max_waves_for(int dc);                             // waves per workgroup the kernel is built for
+int ems_max_waves_for(int dc, int q);                      // waves per workgroup k_decode is built for
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 bool ems_has_occ4_kernel(const EmsPlan &P);

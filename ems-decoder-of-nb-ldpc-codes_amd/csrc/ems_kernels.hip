@@ -1253,7 +1253,8 @@ __host__ __device__ inline int wg_header_bytes(int q, int M) { return 2 * q + 16
 // register allocator pays a few moves for it, so the 12-wave-per-CU shapes keep the roomier build).
 template <int Q, int LPE, int DC, int NM, bool OCC4 = false>
 // (the small GF(64)/dc=4 specialisation runs many 2-wave workgroups per CU: ask for 4 waves per SIMD there)
-__global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? 16 : (LPE == 4 ? 8 : 12)) * 64, (OCC4 || (Q == 64 && DC == 4)) ? 4 : 1) k_decode(const EmsPlan P)
+// (rows of 8 lanes over GF(256) keep 32 symbols per lane: 12 waves = 168 VGPRs instead of the 128 of 16 waves)
+__global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) : (LPE == 4 ? 8 : 12)) * 64, (OCC4 || (Q == 64 && DC == 4)) ? 4 : 1) k_decode(const EmsPlan P)
 {
     using G = Geo<Q, LPE>;
     Cfg C;
@@ -2557,7 +2558,7 @@ template <typename T> hipError_t set_max_lds(T kernel, size_t bytes)
 int ems_lpe_for(int dc) { return dc <= 4 ? 16 : (dc <= 8 ? 8 : (dc <= 16 ? 4 : 0)); }   // dc 9..16: GF(16)/GF(64) only
 // waves per workgroup the decode kernel is compiled for: the dc <= 4 kernels keep q/16 values per lane in
 // registers and need the 170-VGPR budget of 12 waves; the dc <= 8 kernels fit the 128 of 16 waves
-int ems_max_waves_for(int dc) { const int l = ems_lpe_for(dc); return l == 8 ? 16 : (l == 4 ? 8 : 12); }
+int ems_max_waves_for(int dc, int q) { const int l = ems_lpe_for(dc); return l == 8 ? (q >= 256 ? 12 : 16) : (l == 4 ? 8 : 12); }
 
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {
@@ -2616,6 +2617,8 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
     if (spec && P.q == 256 && P.dc == 4 && P.nm == 20) return launch_decode_t<256, 16, 4, 20>(P, B, st);
     if (spec && P.q == 64 && P.dc == 4 && P.nm == 16) return launch_decode_t<64, 16, 4, 16>(P, B, st);
     if (spec && P.q == 16 && P.dc == 8 && P.nm == 8) return launch_decode_t<16, 8, 8, 8>(P, B, st);
+    if (spec && P.q == 256 && P.dc == 8 && P.nm == 20) return launch_decode_t<256, 8, 8, 20>(P, B, st);   // the rate-3/4 GF(256) matrices of the reference
+    if (spec && P.q == 256 && P.dc == 12 && P.nm == 20) return launch_decode_t<256, 4, 12, 20>(P, B, st);  // ... and the rate-5/6 one
     if (lpe == 16) {
         if (P.q == 256) return launch_decode_t<256, 16>(P, B, st);
         if (P.q == 64) return launch_decode_t<64, 16>(P, B, st);
