@@ -2781,6 +2781,7 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
     if (base && P.occ4 && P.waves_per_wg <= 4) return launch_decode_v2_t<256, 16, 20, true>(P, B, st);   // 4 frames per CU
     if (base) return launch_decode_v2_t<256, 16, 20>(P, B, st);
     if (P.q == 256 && lpe == 16) return launch_decode_v2_t<256, 16>(P, B, st);
+    if (P.q == 256 && lpe == 8 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64) return launch_decode_v2_t<256, 8, 20>(P, B, st);   // rate-3/4 matrices, compile-time nm
     if (P.q == 256 && lpe == 8) return launch_decode_v2_t<256, 8>(P, B, st);
     if (P.q == 64 && lpe == 16) return launch_decode_v2_t<64, 16>(P, B, st);
     if (P.q == 64 && lpe == 8) return launch_decode_v2_t<64, 8>(P, B, st);

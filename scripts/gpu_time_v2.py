@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 import bench
-path = os.path.join(ge.MATRICES, "Ahmed_64800_R12_GF256")
+path = os.path.join(ge.MATRICES, os.environ.get("EMS_V2_MATRIX", "Ahmed_64800_R12_GF256"))
 code = pkg.Code(path)
 i2b, _ = pkg.gf_tables(256)
 for B in [int(x) for x in (sys.argv[1:] or ["256"])]:
