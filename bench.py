@@ -44,7 +44,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 
 def kernel_name(workload, B, n_cu=256):
     """The decode kernel the library launches for this workload and batch (ems_core.cpp: shape_for_batch)."""
-    return "k_decode_dual" if workload == "gf256" and (B + n_cu - 1) // n_cu >= 5 and os.environ.get("EMS_DUAL") != "0" else "k_decode"
+    fpc = (B + n_cu - 1) // n_cu                       # frames per CU: 1 -> one 12-wave workgroup per CU, 4 -> the 128-VGPR 4-wave build
+    return "k_decode_dual" if workload == "gf256" and (fpc >= 5 or fpc in (2, 3)) and os.environ.get("EMS_DUAL") != "0" else "k_decode"
 
 
 def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):

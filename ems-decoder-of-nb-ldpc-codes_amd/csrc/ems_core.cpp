@@ -760,6 +760,11 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
     if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 5 && ems_has_dual_kernel(P) &&
         6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 2 KiB units: 27 KiB workgroups ran five to a CU, 13 KiB ones eleven)
+    // two or three frames per CU: the same kernel in 4-wave workgroups, three to a CU (measured on the headline code, frames/s at
+    // batch 512 / 768: 2811 / 3636 against 2403 / 2922 for the one-visit shapes; at 256 the 12-wave one-visit workgroup wins,
+    // 2391 against 1559, and at 1024 its 128-VGPR 4-wave build, 3295 against 2964)
+    if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 2 && fpc <= 3 && ems_has_dual_kernel(P) &&
+        3 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 4) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(4); return; }
     if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
     else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }

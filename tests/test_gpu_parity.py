@@ -416,24 +416,26 @@ def test_two_visits_per_wave_kernel_on_other_dc4_gf256_inputs(pkg, orc, monkeypa
     dec.close()
 
 
-def test_full_size_headline_batch1536_dual_shape_agrees(pkg, orc):
-    """The bench's batch (1536 frames = 6 per CU, fixed work at 1.0 dB) takes the two-visits-per-wave kernel: frame
-    for frame it must give what the one-frame-per-CU launch gives, and the oracle's result on a sampled frame."""
+@pytest.mark.parametrize("B", [1536, 700])
+def test_full_size_headline_dual_shapes_agree(pkg, orc, B):
+    """The bench's batch (1536 frames = 6 per CU, fixed work at 1.0 dB) takes the two-visits-per-wave kernel in 2-wave
+    workgroups, 700 frames (3 per CU) the same kernel in 4-wave workgroups: frame for frame they must give what the
+    one-frame-per-CU launch gives, and the oracle's result on a sampled frame."""
     path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
     o = orc.Oracle(path)
     sigma = o.sigma(1.0)
     rng = orc.Rng(0)
     base = [o.draw_frame(rng, sigma) for _ in range(8)]
-    idx = np.arange(1536) % 8
+    idx = np.arange(B) % 8
     noisy = np.stack([base[i][1] for i in idx])
     code = pkg.Code(path)
-    big = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=1536, early_exit=False)
+    big = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=B, early_exit=False)
     d, it, sy = big.decode_batch(noisy, sigma)
     small = pkg.Decoder(code, 20, 40, 0.3, 6, max_batch=8, early_exit=False)
     d8, it8, sy8 = small.decode_batch(noisy[:8], sigma)
-    for b in range(1536):
+    for b in range(B):
         assert (d[b] == d8[b % 8]).all() and sy[b] == sy8[b % 8] and it[b] == it8[b % 8]
-    for b in (0, 5, 517, 1535):
+    for b in (0, 5, 517, B - 1):
         assert big.app(b).tobytes() == small.app(b % 8).tobytes()
         assert big.ctov(b).tobytes() == small.ctov(b % 8).tobytes()
     ref = o.decode(o.llr(noisy[3], sigma), 20, 40, 0.3, 6, early_exit=False, want_state=True)
