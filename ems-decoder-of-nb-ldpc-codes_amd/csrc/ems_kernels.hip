@@ -980,10 +980,11 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
         const lds_f32 *dl = (const lds_f32 *)(uintptr_t)dbase;
         unsigned S = ~am & (G::EPL >= 32 ? 0xFFFFFFFFu : ((1u << (G::EPL & 31)) - 1u));
         wave_lds_sync();
-        // four survivors per round: their values are requested together (one LDS round trip per round instead of one per
-        // survivor); a lane that has run out reads element 0 and parks it in its dummy slot
+        // two survivors per round: their values are requested together (one LDS round trip per round instead of one per
+        // survivor; measured: 2 per round 388.2 ms per launch, 1 or 4 per round 390.0); a lane that has run out reads element 0
+        // and parks it in its dummy slot
         while (__ballot(S != 0u) != 0ull) {
-            constexpr int R = 4;
+            constexpr int R = 2;
             unsigned symk[R];
             float vk[R];
             bool hk[R];
