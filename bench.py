@@ -144,7 +144,7 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
                "config": {"workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
                           "batch_per_gpu": B, "sharding": "independent frames", "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
                           "frames_nonzero_syndromes_sumiter": counters.cpu().tolist()},
-               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % ("k_decode_v2_dual" if (B + 255) // 256 >= 5 and os.environ.get("EMS_DUAL") != "0" else "k_decode_v2", B),
+               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % ("k_decode_v2_dual" if ((B + 255) // 256 >= 5 or (B + 255) // 256 in (2, 3)) and os.environ.get("EMS_DUAL") != "0" else "k_decode_v2", B),
                             "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
                             "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
                "host_setup_s": round(t_setup, 1)}

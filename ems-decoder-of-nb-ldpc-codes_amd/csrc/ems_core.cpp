@@ -1129,11 +1129,15 @@ int ems_v2_decode(ems_handle *h, int B)
     {   // five or more frames per CU: the two-visits-per-wave kernel (2-wave workgroups, six to a CU), as the main path
         const char *ed = getenv("EMS_DUAL");
         const long fpc = h->n_cu > 0 ? ((long)B + h->n_cu - 1) / h->n_cu : 0;
-        const bool want = ed ? atoi(ed) > 0 : fpc >= 5;
+        // two or three frames per CU: 4-wave workgroups of it, three to a CU (measured at batch 512 / 768: 2418 / 3112 frames/s
+        // against 1843 / 2319 for the one-visit shapes; at 1024 the one-visit 4-wave shape wins, 2617 against 2439)
+        const bool mid = fpc >= 2 && fpc <= 3;
+        const bool want = ed ? atoi(ed) > 0 : (fpc >= 5 || mid);
+        const int wv = ed && atoi(ed) > 0 ? std::min(4, atoi(ed)) : (mid ? 4 : 2);
         if (want && !getenv("EMS_WAVES") && ems_has_v2_dual_kernel(P) &&
-            6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= (size_t)160 * 1024) {
+            (wv == 4 ? 3 : 6) * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, wv == 4 ? 4 : 2) + 2047) & ~(size_t)2047) <= (size_t)160 * 1024) {
             P.dual = 1; P.occ4 = 0;
-            P.waves_per_wg = ed && atoi(ed) > 0 ? std::min(4, atoi(ed)) : 2;
+            P.waves_per_wg = wv;
             P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
         }
     }

@@ -115,10 +115,10 @@ def test_v2_big_code_two_visits_per_wave(pkg, v2, monkeypatch, waves):
     _check_frames(pkg, v2, "Ahmed_64800_R12_GF256", 256, 8, 20, 40, 0.3, 8, [(0.62, 7), (0.78, 11), (0.95, 3)])
 
 
-@pytest.mark.parametrize("B", [1024, 1536])
+@pytest.mark.parametrize("B", [600, 1024, 1536])
 def test_v2_full_size_big_batches_shapes_agree(pkg, v2, B):
-    """1024 frames (four 4-wave workgroups per CU, 128-VGPR build of k_decode_v2) and the bench's 1536 (six 2-wave
-    workgroups per CU of k_decode_v2_dual) against the one-frame-per-CU
+    """600 frames (three 4-wave workgroups per CU of k_decode_v2_dual), 1024 (four 4-wave workgroups per CU, 128-VGPR
+    build of k_decode_v2) and the bench's 1536 (six 2-wave workgroups per CU of k_decode_v2_dual) against the one-frame-per-CU
     launch on 8 distinct frames tiled: decisions, iteration counts, syndromes of every frame and the full state of
     sampled frames agree; one frame is also checked against the oracle."""
     path = os.path.join(MAT, "Ahmed_64800_R12_GF256")
