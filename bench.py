@@ -332,6 +332,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tot = counters.cpu().tolist()
+    # ---- side figure (never `value`): BASELINE.json configs[3] to the letter, the same code at batch = 256 (one frame per CU) ----
+    b256 = None
+    if rank == 0 and world == 1 and a.workload == "gf256" and B > 256 and not a.no_operational:
+        def step256():
+            dec.llr_init_dev(noisy_dev, sigma, 256)
+            dec.decode(256)
+            dec.count_errors_resident(256)
+            return dec.last_decode_ms
+        step256()
+        t1 = time.perf_counter()
+        k256 = [step256() for _ in range(3)]
+        b256 = {"frames_per_s": round(3 * 256 / (time.perf_counter() - t1), 1), "avg_launch_ms": round(float(np.mean(k256)), 3),
+                "kernel": kernel_name(a.workload, 256), "note": "configs[3] as written (batch 256): a latency shape, one 12-wave workgroup per CU"}
     dec.close()     # frees its stream: ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, the side run below wants 3 of its own
 
     # ---- side figure (never `value`): early exit enabled at the operating point of SURVEY.md 8(d) ----
@@ -411,6 +424,8 @@ def main():
         }
         if oper is not None:
             out["config"]["operational_early_exit"] = oper
+        if b256 is not None:
+            out["config"]["batch256_fixed_work"] = b256
         tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tr):
             try:
