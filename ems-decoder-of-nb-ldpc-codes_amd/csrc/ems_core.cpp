@@ -694,7 +694,7 @@ int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float
     if (mode != EMS_LLR_SUM && mode != EMS_LLR_SSD) return fail(EMS_EINVAL, "unknown LLR mode %d (EMS_LLR_NEG belongs to ems_v2_channel_likelihood)", mode);
     if (mode == EMS_LLR_SUM && D != 2) return fail(EMS_EINVAL, "EMS_LLR_SUM is the two-dimensional form (channel.c:277)");
     if (mode == EMS_LLR_SSD && !att_host) return fail(EMS_EINVAL, "EMS_LLR_SSD needs the per-axis attenuations");
-    if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "constellation front ends: GF(64) and GF(256) (the reference's, channel.c:344 / :395)");
+    if (h->q != 16 && h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "constellation front ends: GF(16), GF(64) and GF(256) (the reference's, channel.c:344 / :395 / :520)");
     if (!(sigma > 0.f)) return fail(EMS_EINVAL, "sigma must be > 0");
     if (D > h->logq) return fail(EMS_EINVAL, "D exceeds the staging buffer");
     const size_t n = (size_t)B * h->N * D;

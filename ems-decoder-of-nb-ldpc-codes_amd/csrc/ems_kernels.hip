@@ -2302,7 +2302,7 @@ __global__ void __launch_bounds__(256) k_llr_init(const float *__restrict__ nois
 // with the reference's promotions: differences, products and squares in float, quotient and sum in double.
 // One wavefront per (frame, variable node): the table [q][D] (indexed by the symbol's BINARY IMAGE, as the reference's
 // `som`) sits in LDS, lane i evaluates the images i + 64 h, the results pass through a per-wave LDS row (image -> symbol
-// index) and leave as one coalesced store.  q = 64 or 256.
+// index) and leave as one coalesced store.  q = 16 (ModelChannel's third field, channel.c:520), 64 or 256.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs, const float *__restrict__ att,
                                                    const float *__restrict__ table, int q, int D, int mode, float sigma, size_t nvn,
@@ -2316,7 +2316,7 @@ __global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs
     for (int i = threadIdx.x; i < q; i += blockDim.x) b2i[i] = bin2idx[i];
     __syncthreads();
     const double den = 2.0 * (double)(sigma * sigma);          // 2.0*SQR(sigma), SQR in float (channel.h:13)
-    const int spl = q / 64;                                    // images per lane
+    const int spl = q >= 64 ? q / 64 : 1;                      // images per lane (GF(16): lanes 16.. idle)
     for (size_t v = (size_t)blockIdx.x * 4 + wave; v < nvn; v += (size_t)gridDim.x * 4) {
         float y[4], a[4];
         for (int d = 0; d < D; ++d) {
@@ -2325,6 +2325,7 @@ __global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs
         }
         for (int h = 0; h < spl; ++h) {
             const int img = lane + 64 * h;
+            if (img >= q) break;
             const float *t = tab + img * D;
             float tmp;
             if (mode == 0 || mode == 2) {                       // (a = 1 without attenuations: t * 1.0f is t)
@@ -2347,7 +2348,7 @@ __global__ void __launch_bounds__(256) k_llr_const(const float *__restrict__ obs
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float *dst = app + v * q;
         if (spl == 4) *reinterpret_cast<float4 *>(dst + 4 * lane) = *reinterpret_cast<const float4 *>(&row[wave][4 * lane]);
-        else dst[lane] = row[wave][lane];
+        else if (lane < q) dst[lane] = row[wave][lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

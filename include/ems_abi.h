@@ -81,7 +81,8 @@ int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed t
 int ems_llr_init(ems_handle *h, const float *noisy_host, float sigma, int B);
 int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B);
 /* The constellation front ends of channel.c:112-929 -- LLR part: one GF(q) symbol = one point of a
- * D-dimensional constellation (D = 2: 64-APSK, rotated 64/256-QAM; D = 4: the 4-D 256-QAM), q = 64 or 256.
+ * D-dimensional constellation (D = 2: 64-APSK, rotated 16/64/256-QAM and ModelChannel's other compile-time constellations; D = 4: the
+ * 4-D 256-QAM), q = 16, 64 or 256.
  *   obs   [B][N][D]  received coordinates (the reference's NoisyBin, channel.c:255-266 / :636-670 / :829-856)
  *   att   [B][N][D]  per-axis attenuation as the LLR sees it (fading, 0 = erased axis); may be NULL with EMS_LLR_SUM
  *                    (no fading); with it, EMS_LLR_SUM gives 0 to a node whose attenuation is <= 0 (channel.c:681-684)

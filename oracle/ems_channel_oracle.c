@@ -5,7 +5,9 @@
  *   ModelChannel_AWGN_64          channel.c:112-310   64-APSK (DVB-S2X 8+16+20+20), AWGN, GF(64)
  *   ModelChannel                  channel.c:328-736   as the shipped switches compile it (channel.c:20-26): rotated QAM
  *                                                     (QAM_R), independent Rayleigh fading per axis (rayleigh_fading_SSD)
- *                                                     and erasures, GF(64) / GF(256)
+ *                                                     and erasures, GF(16) / GF(64) / GF(256); and its other switch settings
+ *                                                     (APSK, plain QAM, rayleigh_fading, no erasure), pinned against
+ *                                                     reference builds with those switches (oracle/Makefile CHAN_VARIANTS)
  *   ModelChannel_AWGN_256QAM_4D   channel.c:749-929   4-D rotated 16-QAM x 16-QAM, fading + erasures per axis, GF(256)
  * Parity status: PINNED -- tests/test_channel_oracle.py compares every LLR and the sorted (LLR, symbol) output of whole
  * frames with the REAL functions compiled into oracle/_ref, and tests/golden/channel_const.npz holds reference outputs
@@ -58,6 +60,17 @@ void orc_const_apsk64(const double *radius, const int *num, const int *den, floa
     }
 }
 
+/* channel.c:361-375 (ModelChannel with the APSK switch, GF(256)): 8 rings of 32 points, float radius times the double cosine /
+ * sine of angle*PI/16, stored as float; index = ring*32 + angle = the symbol's binary image.  The radii are fixture data. */
+void orc_const_apsk256(const float *radius8, float *out)
+{
+    for (int ring = 0; ring < 8; ring++)
+        for (int angle = 0; angle < 32; angle++) {
+            out[2 * (ring * 32 + angle) + 0] = (float)((double)radius8[ring] * cos(angle * CH_PI / 16));
+            out[2 * (ring * 32 + angle) + 1] = (float)((double)radius8[ring] * sin(angle * CH_PI / 16));
+        }
+}
+
 /* channel.c:233 / :596 / :810: sigma from the SNR (no code rate here, unlike channel.c:51) */
 float orc_chan_sigma(float EbN) { return (float)sqrt(1.0 / (2.0 * pow(10, (double)EbN / 10.0))); }
 
@@ -66,12 +79,19 @@ float orc_chan_sigma(float EbN) { return (float)sqrt(1.0 / (2.0 * pow(10, (doubl
  * kind 1: ModelChannel, SSD + erasure (channel.c:636-670): per axis u, v, fading draw, erasure draw; the erased /
  *         rescaled attenuation multiplies the point.
  * kind 2: ModelChannel_AWGN_256QAM_4D (channel.c:829-856): per axis u, v, fading draw, the observation uses the RAW
- *         fading, then the erasure draw replaces the stored attenuation (the LLR sees the erased / rescaled one). */
+ *         fading, then the erasure draw replaces the stored attenuation (the LLR sees the erased / rescaled one).
+ * The compile-time variants of ModelChannel the reference ships switched off (channel.c:20-26):
+ * kind 3: `rayleigh_fading` (channel.c:627-631): ONE fading draw per node before its axes, then per axis u, v; the same
+ *         attenuation multiplies both coordinates and is stored for both.
+ * kind 4: `rayleigh_fading_SSD` without `erasure` (channel.c:648-651): per axis u, v, fading draw; no erasure draw.
+ * (no fading switch at all: kind 0 -- the point times the float 1.0 is the point.) */
 void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const int *images, float sigma, float *obs,
                    float *att)
 {
     const float erasure_proba = (float)0.1; /* channel.c:593 / :771 */
-    for (int n = 0; n < N; n++)
+    for (int n = 0; n < N; n++) {
+        float node_a = 1.0f;
+        if (kind == 3) node_a = (float)sqrt(-log((double)my_drand48f(r)));
         for (int d = 0; d < D; d++) {
             const float u = my_drand48f(r);
             const float v = my_drand48f(r);
@@ -80,6 +100,12 @@ void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const
             const double noise = (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * CH_PI * (double)v);
             if (kind == 0) {
                 obs[(size_t)n * D + d] = (float)((double)pt + noise);
+            } else if (kind == 3) {
+                a = node_a;
+                obs[(size_t)n * D + d] = (float)((double)(pt * a) + noise);
+            } else if (kind == 4) {
+                a = (float)sqrt(-log((double)my_drand48f(r)));
+                obs[(size_t)n * D + d] = (float)((double)(pt * a) + noise);
             } else {
                 float rt = my_drand48f(r);
                 a = (float)sqrt(-log((double)rt));
@@ -91,6 +117,7 @@ void orc_chan_draw(orc_rng *r, int kind, const float *table, int D, int N, const
             }
             att[(size_t)n * D + d] = a;
         }
+    }
 }
 
 /* The LLR rows (what the GPU kernel computes).  table [q][D] indexed by binary image; llr [N][q] indexed by symbol.

@@ -1,7 +1,7 @@
 """ctypes bindings of oracle/ems_channel_oracle.c -- TEST INFRASTRUCTURE ONLY.
 
 Constellation channel front ends of the reference (channel.c:112-929).  `Channel` bundles one
-of the three shipped front ends with its constellation table built from the fixture's raw tables exactly as the
+of the three shipped front ends (or one of ModelChannel's switched-off compile-time variants) with its constellation table built from the fixture's raw tables exactly as the
 reference builds it (rotation, normalisation), and splits it the way the product is split: draw() = harness side
 (RNG, modulation, fading, erasures), llr() = the hot-path part the GPU kernel replaces."""
 import ctypes as C
@@ -11,7 +11,9 @@ import numpy as np
 
 import orc
 
-KINDS = {"apsk64": 0, "qamr_ssd": 1, "qam4d": 2}     # ModelChannel_AWGN_64 / ModelChannel / ModelChannel_AWGN_256QAM_4D
+# draw kinds of orc_chan_draw: ModelChannel_AWGN_64 / ModelChannel as shipped / ModelChannel_AWGN_256QAM_4D, then ModelChannel's
+# compile-time variants (channel.c:20-26): APSK + rayleigh_fading, plain QAM without fading, rotated QAM + SSD without erasures
+KINDS = {"apsk64": 0, "qamr_ssd": 1, "qam4d": 2, "apsk_rf": 3, "qam_awgn": 0, "qamr_ssd_ne": 4}
 MODE_SUM, MODE_SSD, MODE_NEG = 0, 1, 2
 
 
@@ -40,11 +42,23 @@ class Channel:
             t = np.zeros((64, 2), np.float32)
             L.orc_const_apsk64(raw["apsk64_radius"].astype(np.float64).ctypes.data_as(C.POINTER(C.c_double)),
                                _i(raw["apsk64_num"].astype(np.int32)), _i(raw["apsk64_den"].astype(np.int32)), _f(t))
-        elif kind == "qamr_ssd":
+        elif kind in ("qamr_ssd", "qamr_ssd_ne"):
             self.D, self.mode = 2, MODE_SSD
             src = np.ascontiguousarray(raw["qam%d" % q], np.float32)
             t = np.zeros((q, 2), np.float32)
             L.orc_const_rotate(_f(src), q, _f(t))
+        elif kind == "qam_awgn":                         # channel.c:377-389 / :502-510 / :539-552, LLR :717
+            self.D, self.mode = 2, MODE_SUM
+            t = np.ascontiguousarray(raw["qam%d" % q], np.float32).copy()
+        elif kind == "apsk_rf":                          # channel.c:361-376 / :417-501, LLR :696-700
+            self.D, self.mode = 2, MODE_SUM
+            t = np.zeros((q, 2), np.float32)
+            if q == 256:
+                L.orc_const_apsk256(_f(np.ascontiguousarray(raw["apsk256_radius"], np.float32)), _f(t))
+            else:
+                assert q == 64
+                L.orc_const_apsk64(raw["apsk64mc_radius"].astype(np.float64).ctypes.data_as(C.POINTER(C.c_double)),
+                                   _i(raw["apsk64mc_num"].astype(np.int32)), _i(raw["apsk64mc_den"].astype(np.int32)), _f(t))
         elif kind == "qam4d":
             assert q == 256
             self.D, self.mode = 4, MODE_SSD

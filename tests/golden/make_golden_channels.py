@@ -33,6 +33,7 @@ def dump_tables():
 #include "channel.h"
 int main(void) {
     int i, d;
+    for (i = 0; i < 16; i++) printf("qam16 %.9g %.9g\n", table_16QAM[i][0], table_16QAM[i][1]);
     for (i = 0; i < 64; i++) printf("qam64 %.9g %.9g\n", table_64QAM[i][0], table_64QAM[i][1]);
     for (i = 0; i < 256; i++) printf("qam256 %.9g %.9g\n", table_256QAM[i][0], table_256QAM[i][1]);
     for (i = 0; i < 256; i++) { printf("qam4d"); for (d = 0; d < 4; d++) printf(" %.9g", table_256QAM_4D_16QAM_R[i][d]); printf("\n"); }
@@ -45,17 +46,26 @@ int main(void) {
         exe = os.path.join(td, "dump")
         subprocess.check_call(["gcc", "-w", "-I" + os.path.join(REF, "include"), "-o", exe, c, "-lm"])
         out = subprocess.check_output([exe]).decode().split("\n")
-    t = {"qam64": [], "qam256": [], "qam4d": []}
+    t = {"qam16": [], "qam64": [], "qam256": [], "qam4d": []}
     for l in out:
         if l.strip():
             k, *v = l.split()
             t[k].append([float(x) for x in v])
-    return (np.array(t["qam64"], np.float32), np.array(t["qam256"], np.float32), np.array(t["qam4d"], np.float32))
+    return (np.array(t["qam16"], np.float32), np.array(t["qam64"], np.float32), np.array(t["qam256"], np.float32), np.array(t["qam4d"], np.float32))
 
 
-def parse_apsk64():
+def parse_apsk256_radii():
+    """channel.c:365: the 8 ring radii of ModelChannel's GF(256) APSK variant."""
     txt = open(os.path.join(REF, "channel.c")).read()
-    body = txt[txt.index("float table_64APSK[64][2]="):]
+    m = re.search(r"float constellation_radius\[8\]=\s*\{([^}]*)\}", txt)
+    r = np.array([float(x) for x in m.group(1).split(",")], np.float32)
+    assert r.shape == (8,)
+    return r
+
+
+def parse_apsk64(decl="float table_64APSK[64][2]="):
+    txt = open(os.path.join(REF, "channel.c")).read()
+    body = txt[txt.index(decl):]
     body = body[:body.index("};")]
     rad, num, den = [], [], []
     for m in re.finditer(r"\{\s*(?:([\d.]+)\s*\*\s*)?cos\(PI\*(\d+)/(\d+)\s*\)", body):
@@ -64,9 +74,10 @@ def parse_apsk64():
     return np.array(rad), np.array(num, np.int32), np.array(den, np.int32)
 
 
-def run_reference(fn, matrix, EbN, seed):
-    """decoder.intrinsic_LLR / intrinsic_GF of one frame from the real function, drand48 reset to X0 = 0."""
-    ref = orc.ref_lib("ubs")
+def run_reference(fn, matrix, EbN, seed, variant=""):
+    """decoder.intrinsic_LLR / intrinsic_GF of one frame from the real function, drand48 reset to X0 = 0.
+    variant: one of oracle/Makefile's CHAN_VARIANTS (ModelChannel compiled with other switches) or "" = as shipped."""
+    ref = orc.ref_lib("ubs_" + variant if variant else "ubs")
     code, table, dec = orc.RefCode(), orc.RefTable(), orc.RefDecoder()
     ref.LoadCode(os.fsencode(os.path.join(MAT, matrix)), C.byref(code))
     ref.LoadTables(C.byref(table), code.GF, code.logGF)
@@ -85,19 +96,28 @@ def run_reference(fn, matrix, EbN, seed):
     return cw, sl, sg
 
 
-CASES = [  # tag, function, matrix, EbN, seed
-    ("apsk64_n96", "ModelChannel_AWGN_64", "N96_K48_GF64", 12.0, 1),
-    ("qamr64_n96", "ModelChannel", "N96_K48_GF64", 14.0, 2),
-    ("qamr256_big", "ModelChannel", "Ahmed_64800_R12_GF256", 20.0, 3),
-    ("qam4d_big", "ModelChannel_AWGN_256QAM_4D", "Ahmed_64800_R12_GF256", 12.0, 4),
+CASES = [  # tag, function, matrix, EbN, seed, variant
+    ("apsk64_n96", "ModelChannel_AWGN_64", "N96_K48_GF64", 12.0, 1, ""),
+    ("qamr64_n96", "ModelChannel", "N96_K48_GF64", 14.0, 2, ""),
+    ("qamr256_big", "ModelChannel", "Ahmed_64800_R12_GF256", 20.0, 3, ""),
+    ("qam4d_big", "ModelChannel_AWGN_256QAM_4D", "Ahmed_64800_R12_GF256", 12.0, 4, ""),
+    ("qamr16_big", "ModelChannel", "Ahmed_64800_R34_GF16", 9.0, 5, ""),                  # the GF(16) branch, channel.c:520-557
+    # ModelChannel's other compile-time variants (oracle/Makefile: CHAN_VARIANTS)
+    ("apskrf256_big", "ModelChannel", "Ahmed_64800_R12_GF256", 22.0, 6, "apsk_rf"),
+    ("apskrf64_n96", "ModelChannel", "N96_K48_GF64", 15.0, 7, "apsk_rf"),
+    ("qamawgn64_n96", "ModelChannel", "N96_K48_GF64", 13.0, 8, "qam_awgn"),
+    ("qamawgn16_big", "ModelChannel", "Ahmed_64800_R34_GF16", 8.0, 9, "qam_awgn"),
+    ("qamrssdne256_big", "ModelChannel", "Ahmed_64800_R12_GF256", 19.0, 10, "qamr_ssd_ne"),
 ]
 
 if __name__ == "__main__":
-    q64, q256, q4d = dump_tables()
+    q16, q64, q256, q4d = dump_tables()
     rad, num, den = parse_apsk64()
-    out = {"qam64": q64, "qam256": q256, "qam256_4d_16qam_r": q4d, "apsk64_radius": rad, "apsk64_num": num, "apsk64_den": den}
-    for tag, fn, matrix, ebn, seed in CASES:
-        cw, sl, sg = run_reference(fn, matrix, ebn, seed)
+    rad2, num2, den2 = parse_apsk64("float table_APSK[64][2]=")          # ModelChannel's own 64-APSK (channel.c:423)
+    out = {"qam16": q16, "qam64": q64, "qam256": q256, "qam256_4d_16qam_r": q4d, "apsk64_radius": rad, "apsk64_num": num, "apsk64_den": den,
+           "apsk64mc_radius": rad2, "apsk64mc_num": num2, "apsk64mc_den": den2, "apsk256_radius": parse_apsk256_radii()}
+    for tag, fn, matrix, ebn, seed, variant in CASES:
+        cw, sl, sg = run_reference(fn, matrix, ebn, seed, variant)
         head = 16 if sl.shape[0] > 64 else sl.shape[0]
         out[tag + "_cw"] = cw.astype(np.int16)
         out[tag + "_ebn"] = np.float32(ebn)

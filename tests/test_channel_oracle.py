@@ -14,7 +14,19 @@ from conftest import GOLD, MAT, ROOT, gold
 CASES = [("apsk64_n96", "apsk64", "ModelChannel_AWGN_64", "N96_K48_GF64"),
          ("qamr64_n96", "qamr_ssd", "ModelChannel", "N96_K48_GF64"),
          ("qamr256_big", "qamr_ssd", "ModelChannel", "Ahmed_64800_R12_GF256"),
-         ("qam4d_big", "qam4d", "ModelChannel_AWGN_256QAM_4D", "Ahmed_64800_R12_GF256")]
+         ("qam4d_big", "qam4d", "ModelChannel_AWGN_256QAM_4D", "Ahmed_64800_R12_GF256"),
+         ("qamr16_big", "qamr_ssd", "ModelChannel", "Ahmed_64800_R34_GF16")]          # ModelChannel's GF(16) branch (channel.c:520)
+# ModelChannel compiled with the switches the reference ships disabled (channel.c:20-26; oracle/Makefile CHAN_VARIANTS):
+# the oracle kind is also the name of the variant library
+VARIANTS = [("apskrf256_big", "apsk_rf", "Ahmed_64800_R12_GF256"),
+            ("apskrf64_n96", "apsk_rf", "N96_K48_GF64"),
+            ("qamawgn64_n96", "qam_awgn", "N96_K48_GF64"),
+            ("qamawgn16_big", "qam_awgn", "Ahmed_64800_R34_GF16"),
+            ("qamrssdne256_big", "qamr_ssd_ne", "Ahmed_64800_R12_GF256")]
+
+
+def field_order(matrix):
+    return 16 if "GF16" in matrix else (64 if "GF64" in matrix else 256)
 
 
 @pytest.fixture(scope="module")
@@ -24,8 +36,7 @@ def chan(orc):
 
 
 def oracle_frame(orc, chan, raw, tag, kind, matrix):
-    q = 64 if "N96" in matrix else 256
-    ch = chan.Channel(kind, q, raw)
+    ch = chan.Channel(kind, field_order(matrix), raw)
     cw = raw[tag + "_cw"].astype(np.int32)
     sigma = ch.sigma(float(raw[tag + "_ebn"]))
     obs, att = ch.draw(orc.Rng(0), cw, sigma)
@@ -48,6 +59,26 @@ def test_oracle_channels_reproduce_reference_outputs(orc, chan, tag, kind, fn, m
         assert (att == 0).mean() > 0.05 and (att > 0).mean() > 0.8
 
 
+@pytest.mark.parametrize("tag,kind,matrix", VARIANTS)
+def test_oracle_channel_variants_reproduce_reference_outputs(orc, chan, tag, kind, matrix):
+    """ModelChannel with the other constellation / fading switches: the fixture holds the outputs of reference builds made
+    by toggling the #defines on the way into the compiler (nothing of the reference is modified or copied)."""
+    raw = gold("channel_const.npz")
+    ch, obs, att, sigma, llr = oracle_frame(orc, chan, raw, tag, kind, matrix)
+    o = orc.Oracle(os.path.join(MAT, matrix))
+    sl, sg = o.sort_llr(llr)
+    head = raw[tag + "_llr_head"].shape[0]
+    assert sl[:head].tobytes() == raw[tag + "_llr_head"].tobytes()
+    assert (sg[:head] == raw[tag + "_gf_head"]).all()
+    assert orc.crc32(sl) == int(raw[tag + "_crc"][0]) and orc.crc32(sg.astype(np.int32)) == int(raw[tag + "_crc"][1])
+    if kind == "qam_awgn":
+        assert (att == 1).all()
+    elif kind == "apsk_rf":
+        assert (att[:, 0] == att[:, 1]).all() and len(np.unique(att[:, 0])) > len(att) // 2     # one draw per node
+    else:
+        assert (att > 0).all() and (att[:, 0] != att[:, 1]).mean() > 0.99                       # per axis, nothing erased
+
+
 def test_erased_axes_are_skipped_and_fully_erased_nodes_give_zero_rows(orc, chan):
     raw = gold("channel_const.npz")
     ch = chan.Channel("qamr_ssd", 64, raw)
@@ -60,19 +91,21 @@ def test_erased_axes_are_skipped_and_fully_erased_nodes_give_zero_rows(orc, chan
     assert llr[1].tobytes() == ((e1 * e1).astype(np.float64) / (2.0 * float(np.float32(0.2) * np.float32(0.2)))).astype(np.float32).tobytes()
 
 
-@pytest.mark.parametrize("tag,kind,fn,matrix", CASES[:3])
-def test_oracle_channels_vs_live_reference(orc, chan, tag, kind, fn, matrix):
+LIVE = [(t, k, f, m, "") for t, k, f, m in CASES[:3] + CASES[4:]] + [(t, k, "ModelChannel", m, k) for t, k, m in VARIANTS]
+
+
+@pytest.mark.parametrize("tag,kind,fn,matrix,variant", LIVE)
+def test_oracle_channels_vs_live_reference(orc, chan, tag, kind, fn, matrix, variant):
     """Other codewords / SNRs than the fixture holds, against the real functions of oracle/_ref."""
-    if not orc.ref_available():
+    if not orc.ref_available() or not os.path.exists(os.path.join(orc.REF_DIR, "libref_ubs_apsk_rf.so")):
         pytest.skip("oracle/_ref not built (reference tree not mounted)")
     sys.path.insert(0, GOLD)
     mg = importlib.import_module("make_golden_channels")
     raw = gold("channel_const.npz")
-    q = 64 if "N96" in matrix else 256
-    ch = chan.Channel(kind, q, raw)
+    ch = chan.Channel(kind, field_order(matrix), raw)
     o = orc.Oracle(os.path.join(MAT, matrix))
     for ebn, seed in ((8.0, 11), (17.5, 12)):
-        cw, sl, sg = mg.run_reference(fn, matrix, ebn, seed)
+        cw, sl, sg = mg.run_reference(fn, matrix, ebn, seed, variant)
         sigma = ch.sigma(ebn)
         obs, att = ch.draw(orc.Rng(0), cw, sigma)
         s2, g2 = o.sort_llr(ch.llr(obs, att, sigma))
