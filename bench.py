@@ -269,6 +269,8 @@ def main():
         return bench_v2(a, pkg, ge, torch, dist, rank, world, local)
     harness = importlib.import_module(ge.PKG_NAME + ".harness")
     mat, nm, nop, off, itmax, ebn, B0 = WORKLOADS[a.workload]
+    if os.environ.get("EMS_BENCH_EBN"):                       # developer knob: the fixed-work step at another operating point
+        ebn = float(os.environ["EMS_BENCH_EBN"])
     B = a.batch or B0
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)

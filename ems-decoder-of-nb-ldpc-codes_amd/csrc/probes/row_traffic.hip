@@ -18,7 +18,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ v4f ld(const v4f *p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
 template <bool NT> __device__ __forceinline__ void st(v4f *p, v4f v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
-// mode bit 0: non-temporal, bit 1: records too, bit 2: sequential rows instead of random
+// mode bit 0: non-temporal, bit 1: records too, bit 2: sequential rows instead of random, bits 4-5: log2 of adjacent rows per pick
 template <bool NT> __global__ void __launch_bounds__(256) k_rows(float *app, uint8_t *recs, int steps, int mode)
 {
     extern __shared__ uint8_t smem[];
@@ -32,7 +32,10 @@ template <bool NT> __global__ void __launch_bounds__(256) k_rows(float *app, uin
         s = s * 1664525u + 1013904223u;
         unsigned r;
         if (mode & 4) r = ((unsigned)(it * nw + wave) * 8u + row) % ROWS;
-        else r = ((s >> 8) + row * 1009u) % ROWS;            // 8 different rows per wave step (same for the 8 lanes of a group)
+        else {
+            const int chunk = 1 << ((mode >> 4) & 3);        // mode bits 4-5: 1, 2, 4 or 8 adjacent rows per pick
+            r = (((s >> 8) + (row / chunk) * 1009u) % (ROWS / chunk)) * chunk + row % chunk;   // 8 rows per wave step (same for the 8 lanes of a group)
+        }
         r = __shfl(r, lane & ~7);
         v4f *p = reinterpret_cast<v4f *>(fa + (size_t)r * ROW_F) + rl;
         v4f x[8];
