@@ -424,6 +424,11 @@ def main():
                          "llr_init_avg_ms": round(float(np.mean(lms)), 3)},
             "host_setup_s": round(t_setup, 1),
         }
+        if a.workload == "gf256":
+            # beside the contract's peak: what the kernel's own access pattern (in-place 1 KiB row updates + 112-byte records) reaches on
+            # this part with no arithmetic at all -- build/row_traffic, profiles/r02_v3_row_traffic_probe.txt
+            out["roofline"]["access_pattern_ceiling"] = {"gbs": 4965.0, "frac": round(achieved / 4965.0, 5),
+                                                         "source": "csrc/probes/row_traffic.hip, profiles/r02_v3_row_traffic_probe.txt"}
         if oper is not None:
             out["config"]["operational_early_exit"] = oper
         if b256 is not None:
