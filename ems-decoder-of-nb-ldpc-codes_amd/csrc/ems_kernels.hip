@@ -628,11 +628,21 @@ __host__ __device__ inline int dual_list_off(int half, int id, int nmp, int dc)
 {
     return id < dc ? (half * dc + id) * nmp : (2 * dc + half * (dual_nlists(dc) - dc) + (id - dc)) * nmp;
 }
+// The first stages of a visit hold its forward and backward step only (the merges M(k) start when the two chains have met):
+// 2 tasks per visit, 4 per wave -- such a stage runs with SIXTEEN lanes per task (the merge is the same serial loop either way,
+// the post-pass then has half the picks per lane), its tasks in entries 0..3 of the stage's row: visit g >> 1, task g & 1.
+#ifndef EMS_NO_WIDE_STAGE
+__host__ __device__ constexpr bool dual_stage_wide(int dc, int t) { return 2 * t + 1 < dc; }
+#else
+__host__ __device__ constexpr bool dual_stage_wide(int, int) { return false; }
+#endif
 // task of 8-lane group grp (visit grp >> 2, task grp & 3) in stage t
 __device__ __forceinline__ uint2 cn_task_dual(int dc, int nmp, int t, int grp)
 {
-    const int half = grp >> 2;
-    const uint2 tk = cn_task(dc, 1, t, grp & 3);                 // nmp = 1: offsets / 8 = list ids
+    const bool wide = dual_stage_wide(dc, t);
+    if (wide && grp >= 4) return uint2{0u, 0u};
+    const int half = wide ? grp >> 1 : grp >> 2;
+    const uint2 tk = cn_task(dc, 1, t, wide ? (grp & 1) : (grp & 3));                 // nmp = 1: offsets / 8 = list ids
     if ((tk.y >> 16) == 0u) return uint2{0u, 0u};
     const int a = (int)(tk.x & 0xFFFFu) / 8, b = (int)(tk.x >> 16) / 8, o = (int)(tk.y & 0xFFFFu) / 8;
     return uint2{(unsigned)(dual_list_off(half, a, nmp, dc) * 8) | ((unsigned)(dual_list_off(half, b, nmp, dc) * 8) << 16),
@@ -654,11 +664,13 @@ template <int TL = 16>
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
                                         int lane, bool literal ST_PARAMS)
 {
-    const int grp = lane / TL;
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     for (int t = 1; t <= C.nsteps; ++t) {
+        const bool wide = TL == 8 && dual_stage_wide(C.dc, t);      // (two-visit waves: see dual_stage_wide)
+        const int grp = wide ? lane / 16 : lane / TL;
         const uint2 task = sched[(t - 1) * 8 + grp];
-        if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
+        if (fast && wide) es_stage_fast<16>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
+        else if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else {
             // literal form: list ids from the byte offsets (es_stage takes entry pointers through ids of stride nmp)
             const int lb = list_stride(C.nm) * 8;
