@@ -1453,9 +1453,12 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decod
 #ifndef EMS_T1X
 #define EMS_T1X 5
 #endif
+#ifndef EMS_T1A
+#define EMS_T1A 3
+#endif
     // first-pass length of the merge: nm + 3 picks; GF(16) sees so many duplicate symbols (16 symbols, 8 wanted) that a third
     // of the stages needed the 8-step continuation -- a longer first pass is cheaper there
-    C.T1 = NM > 0 ? min(P.nbOper, NM + (Q == 16 ? EMS_T1X : 3)) : min(P.nbOper, P.nm + 3);   // (specialised kernels: nbOper >= nm+3)
+    C.T1 = NM > 0 ? min(P.nbOper, NM + (Q == 16 ? EMS_T1X : EMS_T1A)) : min(P.nbOper, P.nm + 3);   // (specialised kernels: nbOper >= nm+3)
     C.q = Q;
     C.nsteps = DUAL_DC - 2;
     C.n_lists = DUAL_NLISTS;
