@@ -7,7 +7,11 @@ and oracle/_ref exist; the GPU box only sees the fixture).
     the 64-APSK table that channel.c:132-199 writes as radius*cos(PI*num/den) literals (parsed from the text);
   * outputs of the three channel front ends the reference compiles -- ModelChannel_AWGN_64, ModelChannel (rotated QAM,
     fading per axis, erasures: the shipped switches of channel.c:20-26) and ModelChannel_AWGN_256QAM_4D -- for seeded
-    codewords: decoder.intrinsic_LLR / intrinsic_GF (head rows in full, CRC-32 of the whole blocks).
+    codewords: decoder.intrinsic_LLR / intrinsic_GF (head rows in full, CRC-32 of the whole blocks);
+  * the same for ModelChannel's GF(16) branch and for ModelChannel compiled with the switches the reference ships disabled
+    (APSK + rayleigh_fading, plain QAM without fading, rotated QAM + SSD without erasure): libraries built by oracle/Makefile
+    (CHAN_VARIANTS) from channel.c streamed through sed into the compiler -- plus the literals those variants need (the 16-QAM
+    table of include/channel.h, ModelChannel's own 64-APSK triples, the 8 ring radii of its GF(256) APSK).
 """
 import ctypes as C
 import os
