@@ -1165,7 +1165,12 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp, DCD) : t * nmp);
     bool big = false;   // some selected value outside [0, 1e4): the visit then uses the literal bubble loop
     float T_sel = __builtin_inff();
+#if defined(EMS_ABL) && EMS_ABL == 5      // ... and no selection either: a fixed list (only with the elementary steps off -- they would choke on its ties)
+    for (int k = rl; k < nm + 2; k += LPE) inl[k] = EmsEntry{k < nm ? (float)k * 0.5f + mvc[0] * 1e-9f : __builtin_inff(), k < nm ? (unsigned)((k * 7 + row * 3 + (lh & 15)) & (Q - 1)) : EMS_S_INVALID};
+    if (false) {
+#else
     if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow, sw)) {
+#endif
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
         wave_lds_sync();
@@ -1197,14 +1202,27 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     unsigned *tbl = reinterpret_cast<unsigned *>(dense);
     for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
     wave_lds_sync();
+#if defined(EMS_ABL) && (EMS_ABL == 1 || EMS_ABL == 5)      // ablation builds (make ablation; timing experiments, results wrong by construction): no elementary steps, the output list of an edge is its input list
+    (void)tbl;
+#else
     cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull ST_ARGS);
+#endif
 
     STAMP(2);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
+#if defined(EMS_ABL) && (EMS_ABL == 1 || EMS_ABL == 5)
+    const EmsEntry *ol = inl;
+    const int stp = nm;
+#else
     const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp, DCD) : oid * nmp);
     const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * dual_nlists(DCD) + oid : oid];
+#endif
     const float dflt = ol[stp - 1].v + C.offset;
+#if defined(EMS_ABL) && EMS_ABL == 3      // no expansion, no stores, no Decision: one word per row keeps the work before alive
+    if (stact && rl == 0) *reinterpret_cast<float *>(rec + EMS_REC_DFLT(nm)) = dflt + mvc[0] + ol[0].v;
+    return;
+#endif
     fill_row<Q, LPE>(drow, rl, dflt);
     wave_lds_sync();
     for (int k = rl; k < stp; k += LPE) {
