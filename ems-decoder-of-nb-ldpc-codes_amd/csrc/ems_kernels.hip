@@ -1806,7 +1806,11 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     // ---- forward / backward / merge elementary steps (:1798-1850), one lane per task ----
     unsigned *seen = reinterpret_cast<unsigned *>(dense);
     const bool fast = C.nbOper <= ES_MAX_STEPS;              // pick areas hold 64 steps; longer runs take the literal form
+#if defined(EMS_ABLV) && EMS_ABLV == 1     // ablation builds of the v2 flavour (timing experiments, results wrong): no elementary steps
+    if (false) {
+#else
     if (fast) {
+#endif
         for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
         wave_lds_sync();
         for (int st = 1; st <= C.nsteps; ++st) {             // TL lanes per task; the dedupe tables stay clean between stages
@@ -1815,7 +1819,11 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
             wave_lds_sync();
         }
     }
+#if defined(EMS_ABLV) && EMS_ABLV == 1
+    for (int st = 1; false && st <= C.nsteps; ++st) {
+#else
     for (int st = 1; !fast && st <= C.nsteps; ++st) {
+#endif
         for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(seen + i) = uint4{0u, 0u, 0u, 0u};
         wave_lds_sync();
         const uint2 tk = sched[(st - 1) * 8 + (lane & 7)];
@@ -1830,8 +1838,13 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     }
 
     // ---- outputs: inverse rotation over the valid prefix (:1854-1870), C->V record (:2135-2141) ----
+#if defined(EMS_ABLV) && EMS_ABLV == 1
+    const EmsEntry *ol = inl;
+    const int stp = nm;
+#else
     const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp, 4) : oid * nmp);
     const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * dual_nlists(4) + oid : oid];
+#endif
     for (int k = rl; k < nm; k += LPE) {
         const EmsEntry e = ol[k];
         const bool valid = k < stp;
@@ -1845,7 +1858,11 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     //      the sweep: both C->V messages of the node are final then (the other one was written by the earlier visitor,
     //      a predecessor of this task).  APP = (likelihood + TMP[first edge]) + TMP[this edge], TMP = -offset except at
     //      the listed symbols.  The APP rows themselves are stored once, by app_decide_v2 when the decode ends. ----
+#if defined(EMS_ABLV) && EMS_ABLV == 2     // no in-visit ComputeAPPLog / Decision
+    if (false) {
+#else
     if (__ballot(lastv) != 0ull) {
+#endif
         float a[G::EPL], c[G::EPL];
         fill_row<Q, LPE>(drow, rl, -C.offset);
         wave_lds_sync();
@@ -1894,9 +1911,13 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     wave_lds_sync();
     bool big = false;
     float T_sel = __builtin_inff();
+#if defined(EMS_ABLV) && EMS_ABLV == 3     // no selection: the old list with a trace of the new values
+    for (int k = rl; k < nm; k += LPE) inl[k].v = inl[k].v + mvc[0] * 1e-12f;
+#else
     if (!select_threshold<Q, LPE, true>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, DUAL || rowact, big, hint, T_sel, drow)) {
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
     }
+#endif
     wave_lds_sync();
     if (rowact && rl == 0) f_hint[(unsigned)edge] = T_sel;
     const float last = -inl[nm - 1].v;                                        // :1545 normalisation to the nm-th value
