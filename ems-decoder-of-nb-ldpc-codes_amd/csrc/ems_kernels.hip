@@ -2089,7 +2089,10 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
     constexpr int LPE = 8, DC = 4;
     constexpr int DUAL_NLISTS = dual_nlists(DC), DUAL_SCHED_BYTES = dual_sched_bytes(DC);
     Cfg C;
-    C.dc = DC; C.nm = NM > 0 ? NM : P.nm; C.nbOper = P.nbOper; C.T1 = NM > 0 ? NM + 3 : min(P.nbOper, P.nm + 3);   // (NM > 0: nbOper >= NM + 3)
+#ifndef EMS_T1V
+#define EMS_T1V 3
+#endif
+    C.dc = DC; C.nm = NM > 0 ? NM : P.nm; C.nbOper = P.nbOper; C.T1 = NM > 0 ? NM + EMS_T1V : min(P.nbOper, P.nm + 3);   // (NM > 0: nbOper >= NM + 3)
     C.q = Q; C.nsteps = DC - 2; C.n_lists = DUAL_NLISTS; C.offset = P.offset;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *t_i2b = smem, *t_b2i = smem + Q;
