@@ -18,7 +18,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ v4f ld(const v4f *p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
 template <bool NT> __device__ __forceinline__ void st(v4f *p, v4f v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
-// mode bit 0: non-temporal, bit 1: records too, bit 2: sequential rows instead of random, bits 4-5: log2 of adjacent rows per pick
+// mode bit 0: non-temporal, bit 1: records too, bit 2: sequential rows instead of random, bits 4-5: log2 of adjacent rows per pick, bit 3: no row writes, bit 6: no row reads
 template <bool NT> __global__ void __launch_bounds__(256) k_rows(float *app, uint8_t *recs, int steps, int mode)
 {
     extern __shared__ uint8_t smem[];
@@ -39,8 +39,13 @@ template <bool NT> __global__ void __launch_bounds__(256) k_rows(float *app, uin
         r = __shfl(r, lane & ~7);
         v4f *p = reinterpret_cast<v4f *>(fa + (size_t)r * ROW_F) + rl;
         v4f x[8];
+        if (!(mode & 64)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = ld<NT>(p + k * 8);
+            for (int k = 0; k < 8; ++k) x[k] = ld<NT>(p + k * 8);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = v4f{(float)it, (float)k, (float)lane, 1.0f};
+        }
         float rv[4] = {0, 0, 0, 0};
         uint8_t *rp = fr + (size_t)((r * 2u + (it & 1)) % NREC) * REC_B;
         if (mode & 2) {
@@ -49,8 +54,10 @@ template <bool NT> __global__ void __launch_bounds__(256) k_rows(float *app, uin
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { x[k].x += 1.0f; acc += x[k].y; }
+        if (!(mode & 8)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) st<NT>(p + k * 8, x[k]);
+            for (int k = 0; k < 8; ++k) st<NT>(p + k * 8, x[k]);
+        }
         if (mode & 2) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const int k = rl + c * 8; if (k < 20) reinterpret_cast<float *>(rp)[k] = rv[c] + 1.0f; }
@@ -76,7 +83,7 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(kern, dim3(frames), dim3(waves * 64), lds_kib * 1024, 0, app, recs, steps, mode);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        const double per_step = 8.0 * 1024 * 2 + ((mode & 2) ? 8.0 * REC_B * 2 : 0.0);
+        const double per_step = 8.0 * 1024 * ((mode & 8) ? 1 : 2) * ((mode & 64) ? 0.5 : 1.0) + ((mode & 2) ? 8.0 * REC_B * 2 : 0.0);
         const double bytes = (double)frames * waves * steps * per_step;
         printf("frames %d waves/wg %d lds %d KiB steps %d mode %d: %.2f ms, %.1f GB/s (read+write, algorithmic)\n", frames, waves, lds_kib, steps, mode, ms, bytes / ms / 1e6);
     }
