@@ -136,6 +136,27 @@ def test_reference_shaped_model_channel_llr_then_decoding(pkg, orc, chan, refapi
     s.close()
 
 
+def test_reference_shaped_model_channel_llr_gf16(pkg, orc, chan, refapi):
+    """The same hoisted symbol on ModelChannel's GF(16) branch (channel.c:520-557) and on one of its switched-off variants."""
+    raw = gold("channel_const.npz")
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")
+    o = orc.Oracle(path)
+    s = refapi.RefSession(path, 8)
+    for kind, ebn in (("qamr_ssd", 18.0), ("qam_awgn", 11.0)):
+        ch = chan.Channel(kind, 16, raw)
+        sigma = ch.sigma(ebn)
+        (cw, obs, att), = _frames(orc, ch, o, sigma, 1, seed=31)
+        sl, sg = s.model_channel_llr(obs, None if kind in NO_ATT else att, ch.table, ch.mode, sigma)
+        llr = ch.llr(obs, att, sigma)
+        osl, osg = o.sort_llr(llr)
+        assert sl.tobytes() == osl.tobytes() and (sg == osg).all()
+        it, decide, synd = s.decoding(8, 16, 0.3)
+        ref = o.decode(llr, 8, 16, 0.3, 8, want_state=True)
+        assert it == ref["iters"] and synd == ref["synd"] and (decide == ref["decide"]).all()
+        assert s.APP.tobytes() == ref["app"].tobytes()
+    s.close()
+
+
 def test_front_end_argument_checks(pkg):
     dec = pkg.Decoder(pkg.Code(os.path.join(MAT, "N96_K48_GF64")), 16, 32, 0.3, 6, max_batch=1)
     obs = np.zeros((1, 16, 2), np.float32); tab = np.zeros((64, 2), np.float32)
