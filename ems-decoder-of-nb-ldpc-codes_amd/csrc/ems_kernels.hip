@@ -1110,20 +1110,37 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     static_assert(!DUAL || LPE == 8 || LPE == 4, "two visits per wave: 2 x 4 rows of 8 lanes or 2 x 8 rows of 4");
     constexpr int DCD = 32 / LPE;                  // check degree of the two-visit layout
     constexpr bool SWZ = DUAL && LPE == 8 && G::VW == 4 && G::NV % 2 == 0;   // swizzled staging rows (dual_row_swz)
-    const int rl = lane & (LPE - 1);
-    const int row = lane / LPE;
-    const int half = DUAL ? row / DCD : 0;
-    const bool rowact = DUAL ? true : row < C.dc;  // the row computes (LDS side)
-    const bool stact = DUAL ? gact : rowact;       // ... and stores its results to HBM
-    const int t = DUAL ? (row % DCD) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
     const int nm = C.nm;
     const int qm1 = Q - 1;
-    const int edge = cn * C.dc + t;
-    // frame bases are wave-uniform (scalar registers); the per-lane part is a 32-bit offset
-    float *app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
-    uint8_t *rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
-    float *drow = dense + row * Q;
-    const int sw = SWZ ? dual_row_swz(row) : 0;   // index swizzle of this staging row (see dual_row_swz)
+    // Everything a lane derives from its position.  RELANE (the GF(64) two-visit kernels): re-derived at each phase from a laundered
+    // lane id -- the compiler otherwise keeps some eighty such values (LDS addresses, lane masks, literals) in VGPRs across the whole
+    // kernel loop; re-deriving them costs ~2 % in instructions and brings these kernels under 128 VGPRs = 4 waves per SIMD.
+#ifndef EMS_NO_RELANE
+    constexpr bool RELANE = DUAL && Q == 64;
+#else
+    constexpr bool RELANE = false;
+#endif
+    int rl, row, half, t, edge, sw;
+    bool rowact, stact;
+    float *app_row, *drow;
+    uint8_t *rec;
+    auto regeo = [&](bool first) {
+        if (!first && !RELANE) return;
+        if constexpr (RELANE) asm volatile("" : "+v"(lane));
+        rl = lane & (LPE - 1);
+        row = lane / LPE;
+        half = DUAL ? row / DCD : 0;
+        rowact = DUAL ? true : row < C.dc;  // the row computes (LDS side)
+        stact = DUAL ? gact : rowact;       // ... and stores its results to HBM
+        t = DUAL ? (row % DCD) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
+        edge = cn * C.dc + t;
+        // frame bases are wave-uniform (scalar registers); the per-lane part is a 32-bit offset
+        app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
+        rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
+        drow = dense + row * Q;
+        sw = SWZ ? dual_row_swz(row) : 0;   // index swizzle of this staging row (see dual_row_swz)
+    };
+    regeo(true);
 
     // ---- Mvc = APP - CtoV (NB_LDPC.c:329-337); CtoV is all-zero in the first sweep (:273-279).
     //      Every HBM read of the visit (APP row, record header, the nm record entries) is issued
@@ -1160,6 +1177,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     }
 
     STAMP(0);
+    regeo(false);
     // ---- nm smallest in ascending order, ties -> lowest symbol (NB_LDPC.c:354-369) ----
     const int nmp = list_stride(nm);
     EmsEntry *inl = lists + (DUAL ? dual_list_off(half, t, nmp, DCD) : t * nmp);
@@ -1196,6 +1214,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     wave_lds_sync();
 
     STAMP(1);
+    regeo(false);
     // ---- forward / backward / merge elementary steps (bubble_decoder.c:166-227) ----
     // the dense staging rows are dead until the expansion below: their first 4Q words serve as the four dedupe
     // tables of the elementary steps, zeroed here and kept all-zero from stage to stage
@@ -1209,6 +1228,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 #endif
 
     STAMP(2);
+    regeo(false);
     // ---- inverse rotation, q-wide expansion with default LLR[Stp-1]+offset (:231-278), store the
     //      compact C->V record (NB_LDPC.c:434-440) and APP = Mcv + Mvc (:444-450) ----
 #if defined(EMS_ABL) && (EMS_ABL == 1 || EMS_ABL == 5)
@@ -1457,10 +1477,13 @@ __host__ __device__ inline int dual_wave_bytes(int q, int dc, int nm)
     return dual_dense_bytes(q, dc) + 2 * dc * nmp * 8 + (other > survb ? other : ((survb + 15) & ~15));
 }
 
-// DC = 4 (GF(256) headline): at most four waves per workgroup, 168 VGPRs for three waves per SIMD.
+#ifndef EMS_Q64_BLOCKS
+#define EMS_Q64_BLOCKS 4
+#endif
+// DC = 4 (GF(256) headline): at most four waves per workgroup, 168 VGPRs for three waves per SIMD (GF(64): 128 for four, see RELANE).
 // DC = 8 (GF(16), 4 symbols per lane): up to 16 waves per workgroup.
 template <int Q, int NM, int DC>
-__global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? 3 : 1) k_decode_dual(const EmsPlan P)
+__global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? (Q == 64 ? EMS_Q64_BLOCKS : 3) : 1) k_decode_dual(const EmsPlan P)
 {
     constexpr int LPE = 32 / DC;
     constexpr int DUAL_DC = DC, DUAL_NLISTS = dual_nlists(DC), DUAL_SCHED_BYTES = dual_sched_bytes(DC);
