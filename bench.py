@@ -45,7 +45,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 def kernel_name(workload, B, n_cu=256):
     """The decode kernel the library launches for this workload and batch (ems_core.cpp: shape_for_batch)."""
     fpc = (B + n_cu - 1) // n_cu                       # frames per CU: 1 -> one 12-wave workgroup per CU, 4 -> the 128-VGPR 4-wave build
-    return "k_decode_dual" if workload == "gf256" and (fpc >= 5 or fpc in (2, 3)) and os.environ.get("EMS_DUAL") != "0" else "k_decode"
+    nodual = os.environ.get("EMS_DUAL") == "0"
+    if workload == "n96" and B >= 4 * n_cu:                   # tiny code: two frames per wave, else pairs walked by one wave
+        return "k_decode_twin" if os.environ.get("EMS_TWIN") != "0" and not os.environ.get("EMS_DUAL") else ("k_decode" if nodual else "k_decode_dual")
+    if workload == "gf16":
+        return "k_decode" if nodual else "k_decode_dual"
+    return "k_decode_dual" if workload == "gf256" and (fpc >= 5 or fpc in (2, 3)) and not nodual else "k_decode"
 
 
 def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):
@@ -417,7 +422,7 @@ def main():
                        "batch_per_gpu": B, "sharding": "independent frames, contiguous batches per rank",
                        "collective": "all-reduce of 5 int64 error counters per step" if world > 1 else "none",
                        "frames_errframes_biterrs_undetected_sumiter": tot},
-            "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % (kernel_name(a.workload, B), B),
+            "roofline": {"bound": "hbm", "kernel": "%s (persistent, %s, %d frames per launch)" % (kernel_name(a.workload, B), "1 wave per 2 frames" if kernel_name(a.workload, B) == "k_decode_twin" else "1 workgroup per frame", B),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3),

@@ -735,6 +735,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
 {
     P.occ4 = 0;
     P.dual = 0;
+    P.twin = 0;
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
     };
@@ -753,6 +754,16 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     if (allow_dual && !(ed && atoi(ed) == 0) && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }
     // a code whose levels hold a handful of check nodes (the N = 96 bits GF(64) code: 8 check nodes, levels of 1-3) keeps a workgroup of
     // one wave busy at best: one wave walking the pairs in order, two visits at a time (measured 1.72e6 against 1.42e6 frames/s)
+    {   // ... and where pairing inside one frame leaves slots empty (that code: six pair slots for eight check nodes), one wave takes two
+        // FRAMES instead and walks the check nodes in reference order (k_decode_twin).  EMS_TWIN=1 forces it at any batch, EMS_TWIN=0 forbids it.
+        const char *et = getenv("EMS_TWIN");
+        const bool sparse_pairs = P.n_pairs > 0 && 10 * P.n_pairs > 6 * h->M;          // more than a fifth of the slots would be empty
+        if (allow_dual && ems_has_twin_kernel(P) && !(ed && atoi(ed) > 0) &&
+            (et ? atoi(et) > 0 : (sparse_pairs && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu))) {
+            P.twin = 1; P.waves_per_wg = 1; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
+            return;
+        }
+    }
     if (allow_dual && !(ed && atoi(ed) == 0) && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu && ems_has_dual_kernel(P)) { go_dual(1); return; }
     if (ems_lpe_for(h->dc) != 16 || P.waves_per_wg < 12 || h->n_cu <= 0) return;   // (the batch shapes below belong to the dc <= 4 kernels)
     const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);

@@ -1633,6 +1633,115 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? (Q == 64 ? EMS
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TWO FRAMES per wave (k_decode_twin; tiny codes, dc = 4).  The N = 96 bits code has 8 check nodes in dependency levels of
+// 1, 3, 3, 1: pairing check nodes of ONE frame needs six pair slots for them, four of which hold a single check node.  Here a
+// wave owns frames 2w and 2w+1 and walks the check nodes in reference order (NB_LDPC.c:320): rows 0..3 are the edges of the
+// check node in the first frame, rows 4..7 the same edges in the second -- always independent, every slot full, no schedule
+// table, no dependency flags, no claims.  A frame that has converged (or does not exist: odd batch) keeps computing with
+// its stores masked.  Everything else is process_cn<.., DUAL> with a per-lane frame index.
+// LDS carve: [idx2bin Q][bin2idx Q][first_bad of frame 0, of frame 1, pad][schedule] then the wave's region as k_decode_dual.
+// ------------------------------------------------------------------------------------------------
+template <int Q, int NM, int DC>
+__global__ void __launch_bounds__(64, Q == 64 ? 16 : 12) k_decode_twin(const EmsPlan P, int B)
+{
+    static_assert(DC == 4, "rows of 8 lanes");
+    constexpr int LPE = 32 / DC;
+    constexpr int DUAL_NLISTS = dual_nlists(DC);
+    Cfg C;
+    C.dc = DC;
+    C.nm = NM;
+    C.nbOper = P.nbOper;
+    C.T1 = min(P.nbOper, NM + 3);
+    C.q = Q;
+    C.nsteps = DC - 2;
+    C.n_lists = DUAL_NLISTS;
+    C.offset = P.offset;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *t_i2b = smem;
+    uint8_t *t_b2i = smem + Q;
+    unsigned *first_bad = reinterpret_cast<unsigned *>(smem + 2 * Q);      // [2]
+    uint2 *sched = reinterpret_cast<uint2 *>(smem + 2 * Q + 16);
+    const int lane = threadIdx.x;
+    const int rl = lane & (LPE - 1);
+    const int row = lane / LPE;
+    const int half = row / DC;
+    const int t = row % DC;
+    const int oid = P.out_list[t];
+    const int f0 = 2 * (int)blockIdx.x;
+    const bool two = f0 + 1 < B;
+    const int fl = f0 + ((half != 0 && two) ? 1 : 0);          // this lane's frame (the second half shadows the first when there is none)
+
+    const int nmp = list_stride(C.nm);
+    uint8_t *wbase = smem + dual_header_bytes(Q, DC, 0);
+    float *dense = reinterpret_cast<float *>(wbase);
+    EmsEntry *lists = reinterpret_cast<EmsEntry *>(wbase + dual_dense_bytes(Q, DC));
+    uint8_t *other = wbase + dual_dense_bytes(Q, DC) + 2 * DC * nmp * 8;
+    EmsEntry *surv = reinterpret_cast<EmsEntry *>(other);
+    int *lens = reinterpret_cast<int *>(other + 2 * (DUAL_NLISTS - DC) * nmp * 8);
+    uint8_t *picks = reinterpret_cast<uint8_t *>(lens) + ((2 * DUAL_NLISTS * 4 + 15) & ~15);
+
+    for (int i = lane; i < Q; i += 64) {
+        t_i2b[i] = P.idx2bin[i];
+        t_b2i[i] = P.bin2idx[i];
+    }
+    cn_sched_build_dual(sched, DC, C.nm, lane, 64);
+    if (lane < 2) first_bad[lane] = 0xFFFFFFFFu;
+    __syncthreads();
+
+#ifdef EMS_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
+    bool run0 = true, run1 = two;                              // (wave-uniform) the frame is still being decoded
+    int it0 = P.nsweeps + 1, it1 = P.nsweeps + 1;              // value added to sum_it when the frame never converges (NB_LDPC.c:474)
+    unsigned synd0 = 0, synd1 = 0;
+    for (int sweep = 0; sweep < P.nsweeps; ++sweep) {          // NB_LDPC.c:314
+        const bool gact = half ? run1 : run0;
+        for (int c = 0; c < P.M; ++c) {                        // NB_LDPC.c:320, reference order
+            const int vn = P.cn_vn[c * DC + t];
+            const int lh = P.cn_lh[c * DC + t];
+            process_cn<Q, LPE, true>(P, C, fl, c, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
+        }
+        // ---- Syndrom (tools.c:284-299) of both frames: lanes 0..31 take the check nodes of the first, 32..63 of the second ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        const int fs = f0 + ((lane >= 32 && two) ? 1 : 0);
+        for (int c = lane & 31; c < P.M; c += 32) {
+            unsigned acc = 0;
+            for (int i = 0; i < DC; ++i) {
+                const int ed = c * DC + i;
+                const int x = P.decide[(size_t)fs * P.N + P.cn_vn[ed]];
+                acc ^= t_i2b[gf_mul_log(x, P.cn_lh[ed], Q - 1)];
+            }
+            if (acc) atomicMin(&first_bad[lane >> 5], ((unsigned)c << 8) | t_b2i[acc]);
+        }
+        __syncthreads();
+        const unsigned fb0 = first_bad[0], fb1 = first_bad[1];
+        __syncthreads();
+        if (lane < 2) first_bad[lane] = 0xFFFFFFFFu;
+        if (run0) synd0 = (fb0 == 0xFFFFFFFFu) ? 0u : (fb0 & 0xFFu);
+        if (run1) synd1 = (fb1 == 0xFFFFFFFFu) ? 0u : (fb1 & 0xFFu);
+        if (P.early_exit) {                                    // NB_LDPC.c:470-471, frame by frame
+            if (run0 && synd0 == 0) { it0 = sweep + 1; run0 = false; }
+            if (run1 && synd1 == 0) { it1 = sweep + 1; run1 = false; }
+            if (!run0 && !run1) break;
+        }
+    }
+#ifdef EMS_STAMPS
+    if (lane == 0 && P.stamps)
+        for (int i = 0; i < 16; ++i) atomicAdd(&P.stamps[i], st_acc[i]);
+#endif
+    if (lane == 0) {
+        P.iters[f0] = it0;
+        P.synd[f0] = (int)synd0;
+        if (two) {
+            P.iters[f0 + 1] = it1;
+            P.synd[f0 + 1] = (int)synd1;
+        }
+    }
+}
+
 // ================================================================================================
 // v2 flavour: the decode core of EMS_HS_L-BubbleCheck_UBS_decoder_v2.c --
 // max-is-best log-likelihoods, nm-long messages in both directions, 4-candidate bubble check, the same
@@ -2680,6 +2789,17 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const Em
     hipLaunchKernelGGL((k_decode_dual<Q, NM, DC>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
+// two frames per wave (k_decode_twin): the tiny GF(64) dc = 4 codes at nm = 16
+bool ems_has_twin_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 64 && P.dc == 4 && P.nm == 16 && P.M <= 64; }
+size_t ems_twin_wg_lds_bytes(int q, int dc, int nm) { return (size_t)dual_header_bytes(q, dc, 0) + (size_t)dual_wave_bytes(q, dc, nm); }
+template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    const size_t lds = ems_twin_wg_lds_bytes(Q, DC, NM);
+    hipError_t e = set_max_lds(k_decode_twin<Q, NM, DC>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_twin<Q, NM, DC>), dim3((B + 1) / 2), dim3(64), lds, st, P, B);
+    return hipGetLastError();
+}
 // kernels that also exist in the 16-waves-per-CU build
 bool ems_has_occ4_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == 4 && P.nm == 20; }
 
@@ -2688,6 +2808,10 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
     const bool spec = spec_ok(P);
+    if (P.twin) {
+        if (!ems_has_twin_kernel(P)) return hipErrorInvalidValue;
+        return launch_decode_twin_t<64, 16, 4>(P, B, st);
+    }
     if (P.dual) {
         if (!ems_has_dual_kernel(P) || P.waves_per_wg > ems_dual_max_waves(P.dc) || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.dc, P.nm))
             return hipErrorInvalidValue;

@@ -51,6 +51,7 @@ struct EmsPlan {
     // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)
+    int twin;               // launch k_decode_twin: one wave per PAIR OF FRAMES, check nodes in reference order (tiny codes)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)
     const int *p_vn;        // [n_pairs*2dc] variable nodes, row = member * dc + edge
     const int *p_lh;        // [n_pairs*2dc] log of the coefficients

@@ -478,6 +478,20 @@ def test_decode_n96_two_visits_per_wave_vs_oracle(pkg, orc, monkeypatch):
         _decode_vs_oracle(pkg, orc, "KN_N96_K48_GF64.txt", 16, 32, 0.3, 30, -3.0, 8, state=True, early_exit=False)
 
 
+def test_decode_n96_two_frames_per_wave_vs_oracle(pkg, orc, monkeypatch):
+    """k_decode_twin (one wave = two frames, check nodes in reference order; picked by itself from 4 frames per CU on for codes
+    whose pairs would be mostly singles): forced here at small batches -- even and odd, frames that stop at different sweeps
+    sharing a wave, fixed work, the other on-disk layout -- with the full state against the oracle."""
+    monkeypatch.setenv("EMS_TWIN", "1")
+    it = _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 10, 2.0, 96, state=True)
+    assert len(set(it.tolist())) > 2
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 30, 1.0, 47, state=True)                       # odd batch: the last wave has one frame
+    _decode_vs_oracle(pkg, orc, "KN_N96_K48_GF64.txt", 16, 32, 0.3, 30, -3.0, 9, state=True, early_exit=False)
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 19, 1.0, 12, 3.0, 1, state=True)                       # one frame, NbOper = nm + 3
+    monkeypatch.setenv("EMS_TWIN", "0")
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 16, 32, 0.3, 10, 2.0, 8, state=True)                       # (and the knob that forbids it)
+
+
 def test_two_visit_kernels_random_parameter_sweep(pkg, orc, monkeypatch):
     """Seeded random (NbOper, offset, NbIterMax, Eb/N0, early exit, workgroup shape) through the two-visits-per-wave builds on
     small codes of their three families -- GF(256) dc 4 nm 20, GF(64) dc 4 nm 16, and (one frame of the long code) GF(16) dc 8
