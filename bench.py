@@ -15,8 +15,12 @@ independent, so ranks share nothing on the data path ("scaling": "weak"); per st
 the five error counters over RCCL, as the Monte-Carlo harness does.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the persistent decode kernel, timed
-with HIP events on the stream it runs on) and `cpu_baseline` (the oracle, i.e. the CPU port of the
-reference path, on a bounded sample of the same workload; N=1 only).
+with HIP events on the stream it runs on; its name and workgroup shape are asked from the library) and
+`cpu_baseline` (the oracle, i.e. the CPU port of the reference path, and the reference's own executable,
+on a bounded sample of the same workload; N=1 only).  The line checks itself: `counters_match_golden`
+says whether the error counters of the timed run equal the CPU oracle's on the same frames
+(tests/golden/bench_counters.json).  At N=1 `config.other_workloads` carries short runs of BASELINE
+configs[1] (N96, batch 8192) and configs[2] (GF(16), batch 256), each with its own `roofline`.
 """
 import argparse
 import importlib
@@ -40,17 +44,6 @@ WORKLOADS = {
     "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1536),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-
-
-def kernel_name(workload, B, n_cu=256):
-    """The decode kernel the library launches for this workload and batch (ems_core.cpp: shape_for_batch)."""
-    fpc = (B + n_cu - 1) // n_cu                       # frames per CU: 1 -> one 12-wave workgroup per CU, 4 -> the 128-VGPR 4-wave build
-    nodual = os.environ.get("EMS_DUAL") == "0"
-    if workload == "n96" and B >= 4 * n_cu:                   # tiny code: two frames per wave, else pairs walked by one wave
-        return "k_decode_twin" if os.environ.get("EMS_TWIN") != "0" and not os.environ.get("EMS_DUAL") else ("k_decode" if nodual else "k_decode_dual")
-    if workload == "gf16":
-        return "k_decode" if nodual else "k_decode_dual"
-    return "k_decode_dual" if workload == "gf256" and (fpc >= 5 or fpc in (2, 3)) and not nodual else "k_decode"
 
 
 def algorithmic_bytes_per_frame_decode(E, q, nm, sweeps):
@@ -149,14 +142,19 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
                "config": {"workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
                           "batch_per_gpu": B, "sharding": "independent frames", "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
                           "frames_nonzero_syndromes_sumiter": counters.cpu().tolist()},
-               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d frames per launch)" % ("k_decode_v2_dual" if ((B + 255) // 256 >= 5 or (B + 255) // 256 in (2, 3)) and os.environ.get("EMS_DUAL") != "0" else "k_decode_v2", B),
+               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d waves per workgroup, %d frames per launch on %d CUs)" % (dec.last_kernel, dec.last_workgroup_waves, B, dec.n_cu),
                             "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
                             "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
                "host_setup_s": round(t_setup, 1)}
         tr = os.path.join(ROOT, "profiles", "traffic_gf256_v2.json")
+        out["roofline"]["traffic_source"] = None
         if os.path.exists(tr):
             try:
-                out["roofline"]["traffic"] = int(json.load(open(tr))["hbm_bytes_per_frame"] * B)
+                tj = json.load(open(tr))
+                if tj["kernel"].split("::")[-1].split("(")[0] == dec.last_kernel:
+                    out["roofline"]["traffic"] = int(tj["hbm_bytes_per_frame"] * B)
+                    out["roofline"]["traffic_source"] = ("profiles/traffic_gf256_v2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at %d "
+                                                         "frames per launch, scaled per frame (committed measurement, not this run)" % tj["frames_per_launch"])
             except Exception:
                 pass
         if world == 1 and not a.no_cpu_baseline:
@@ -196,29 +194,52 @@ def cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads):
 def reference_executable_rate(orc, matrix, nm, nop, off, itmax, ebn, procs, frames_each=2):
     """The REAL reference (oracle/_ref/essai_ubs, compiled from /root/reference by oracle/Makefile; travels to the GPU box as a
     built binary) timed beside the port: `procs` copies of the executable, one per core, `frames_each` frames each of the
-    same workload (its whole per-frame path: source, encoder, channel, decode; the one-off set-up of every process --
-    loader, tables, Gaussian elimination -- is inside the wall time).  None when the binary is not there."""
+    same workload (its whole per-frame path: source, encoder, channel, decode).  The one-off set-up of a process (loader,
+    tables, Gaussian elimination) is timed by a 0-frame run of the same `procs` copies and subtracted, so `value` is the
+    steady-state rate; both walls are in `sample`.  The printed avr_it must say that every frame ran all sweeps.  None when
+    the binary is not there or anything goes wrong."""
+    import re
     import subprocess
     exe = orc.ref_binary("ubs")
     if not os.path.exists(exe):
         return None
     run = os.path.join(os.path.dirname(exe), "run")
     os.makedirs(os.path.join(run, "data"), exist_ok=True)
-    cmd = [exe, str(frames_each), str(itmax), matrix, str(ebn), str(nm), str(off), str(nop)]
-    t0 = time.time()
-    ps = [subprocess.Popen(cmd, cwd=run, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
-    for p in ps:
-        try:
-            p.communicate(b"\n", timeout=300)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            return None
-    dt = time.time() - t0
-    if any(p.returncode != 0 for p in ps):
+
+    def wall(frames):
+        cmd = [exe, str(frames), str(itmax), matrix, str(ebn), str(nm), str(off), str(nop)]
+        t0 = time.time()
+        ps = [subprocess.Popen(cmd, cwd=run, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(procs)]
+        outs, ok = [], True
+        for p in ps:
+            try:
+                outs.append(p.communicate(b"\n", timeout=300)[0].decode("latin-1"))
+            except subprocess.TimeoutExpired:
+                ok = False
+                break
+        if not ok:
+            for p in ps:                                # no orphans: every copy is killed and reaped
+                p.kill()
+            for p in ps:
+                try:
+                    p.communicate(timeout=10)
+                except Exception:
+                    pass
+            return None, None
+        if any(p.returncode != 0 for p in ps):
+            return None, None
+        return time.time() - t0, outs
+
+    t_setup, _ = wall(0)
+    t_all, outs = wall(frames_each)
+    if t_setup is None or t_all is None or t_all <= t_setup:
         return None
-    return {"value": round(procs * frames_each / dt, 4), "unit": "frames/s", "cores": procs, "kind": "reference",
-            "sample": "%d processes x %d frames of the reference executable (early exit on, %.1f dB: every frame runs all %d sweeps), %.1f s wall incl. its set-up"
-                      % (procs, frames_each, ebn, itmax - 1, dt)}
+    its = [re.findall(r"avr_it=([\d.]+)", o) for o in outs]
+    full = all(it and abs(float(it[-1]) - itmax) < 1e-6 for it in its)   # a non-converged frame counts NbIterMax (NB_LDPC.c:474)
+    return {"value": round(procs * frames_each / (t_all - t_setup), 4), "unit": "frames/s", "cores": procs, "kind": "reference",
+            "all_sweeps_ran": bool(full),
+            "sample": "%d processes x %d frames of the reference executable at %.1f dB (early exit on; avr_it printed = %s): %.1f s wall, of which "
+                      "%.1f s set-up (0-frame run) subtracted" % (procs, frames_each, ebn, its[0][-1] if its and its[0] else "?", t_all, t_setup)}
 
 
 class c_stdout_to_stderr:
@@ -237,46 +258,21 @@ class c_stdout_to_stderr:
         os.close(self.saved)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="gf256", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-operational", action="store_true",
-                    help="skip the side measurement with early exit enabled (SURVEY.md 8(d) 'operational' figure)")
-    ap.add_argument("--synthetic-zero-codeword", action="store_true",
-                    help="skip the host encoder: all-zero codeword + numpy AWGN (faster set-up, same work)")
-    a = ap.parse_args()
+def load_bench_golden(workload):
+    """tests/golden/bench_counters.json (tests/golden/make_bench_golden.py): the five harness counters the CPU oracle gives on
+    this workload's first batch of the drand48 stream."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_counters.json"))).get(workload)
+    except Exception:
+        return None
 
-    import torch  # first: its bundled libamdhip64 must be the one the decoder library binds to
-    import __graft_entry__ as ge
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the decoder library has no CPU fallback")
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or os.environ.get("EMS_BENCH_FORCE_DIST"):      # the env knob rehearses the RCCL path on one GPU
-        import torch.distributed as dist
-        with c_stdout_to_stderr():                  # RCCL prints its version banner on stdout when the communicator comes up
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    pkg = ge.load_package()
-    if a.workload == "gf256_v2":
-        return bench_v2(a, pkg, ge, torch, dist, rank, world, local)
-    harness = importlib.import_module(ge.PKG_NAME + ".harness")
-    mat, nm, nop, off, itmax, ebn, B0 = WORKLOADS[a.workload]
-    if os.environ.get("EMS_BENCH_EBN"):                       # developer knob: the fixed-work step at another operating point
+def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, workload, B, steps, warmup, side_figures):
+    """Timed fixed-work steps of one workload of the main decode path on this rank's GPU: returns what rank 0 prints."""
+    mat, nm, nop, off, itmax, ebn, _B0 = WORKLOADS[workload]
+    ebn_overridden = bool(os.environ.get("EMS_BENCH_EBN"))
+    if ebn_overridden:                                        # developer knob: the fixed-work step at another operating point
         ebn = float(os.environ["EMS_BENCH_EBN"])
-    B = a.batch or B0
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)
     dec = pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False)
@@ -302,17 +298,16 @@ def main():
     dec.synchronize()
     noisy_dev = dec.noisy_dev_ptr
     counters = torch.zeros(5, dtype=torch.int64, device="cuda")
+    local_counts = [None]
 
     def step():
         dec.llr_init_dev(noisy_dev, sigma, B)
         dec.decode(B)
         nberr = dec.count_errors_resident(B)                      # syncs the decoder's stream
-        _d, iters, synd = None, None, None
         it = np.zeros(B, np.int32); sy = np.zeros(B, np.int32)
         pkg._check(pkg.lib().ems_get_results(dec.h, B, None, pkg._ptr(it), pkg._ptr(sy)))
-        loc = torch.tensor([B, int((nberr != 0).sum()), int(nberr.sum()), int(((nberr != 0) & (sy == 0)).sum()), int(it.sum())],
-                           dtype=torch.int64)
-        counters.copy_(loc)
+        local_counts[0] = [B, int((nberr != 0).sum()), int(nberr.sum()), int(((nberr != 0) & (sy == 0)).sum()), int(it.sum())]
+        counters.copy_(torch.tensor(local_counts[0], dtype=torch.int64))
         if dist is not None:
             dist.all_reduce(counters)                             # RCCL, 40 bytes
         return dec.last_decode_ms, dec.last_llr_ms
@@ -324,12 +319,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
     kms, lms = [], []
-    for _ in range(a.steps):
+    for _ in range(steps):
         k, l = step()
         kms.append(k); lms.append(l)
     fence()
@@ -339,9 +334,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tot = counters.cpu().tolist()
+    kernel = dec.last_kernel                                       # what the library launched, from the library
+    wg_waves = dec.last_workgroup_waves
+    n_cu = dec.n_cu
+
+    # ---- self-check: this rank's counters of the timed run against the oracle's (committed golden; rank 0's frame range) ----
+    gold = load_bench_golden(workload)
+    comparable = (gold is not None and not a.synthetic_zero_codeword and not ebn_overridden and gold["batch"] == B
+                  and [gold["nm"], gold["NbOper"], gold["NbIterMax"]] == [nm, nop, itmax])
+    match = None
+    if rank == 0 and comparable:
+        match = local_counts[0] == gold["frames_errframes_biterrs_undetected_sumiter"]
+
     # ---- side figure (never `value`): BASELINE.json configs[3] to the letter, the same code at batch = 256 (one frame per CU) ----
     b256 = None
-    if rank == 0 and world == 1 and a.workload == "gf256" and B > 256 and not a.no_operational:
+    if side_figures and rank == 0 and world == 1 and workload == "gf256" and B > 256:
         def step256():
             dec.llr_init_dev(noisy_dev, sigma, 256)
             dec.decode(256)
@@ -351,13 +358,14 @@ def main():
         t1 = time.perf_counter()
         k256 = [step256() for _ in range(3)]
         b256 = {"frames_per_s": round(3 * 256 / (time.perf_counter() - t1), 1), "avg_launch_ms": round(float(np.mean(k256)), 3),
-                "kernel": kernel_name(a.workload, 256), "note": "configs[3] as written (batch 256): a latency shape, one 12-wave workgroup per CU"}
+                "kernel": dec.last_kernel, "workgroup_waves": dec.last_workgroup_waves,
+                "note": "configs[3] as written (batch 256 = one frame per CU): bound by the frame's dependency chain, see DESIGN.md 4.1"}
     dec.close()     # frees its stream: ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, the side run below wants 3 of its own
 
     # ---- side figure (never `value`): early exit enabled at the operating point of SURVEY.md 8(d) ----
     oper = None
-    OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}[a.workload]
-    if rank == 0 and world == 1 and not a.no_operational and not a.synthetic_zero_codeword:
+    OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}[workload]
+    if side_figures and rank == 0 and world == 1 and not a.synthetic_zero_codeword:
         nd = min(256, B)
         with c_stdout_to_stderr():
             src = harness.FrameSource(matrix, nm)
@@ -405,49 +413,119 @@ def main():
                 "note": "early exit on (NB_LDPC.c:470); reported beside, never instead of, the fixed-work value"}
         for od in ods:
             od.close()
+
+    sweeps = itmax - 1
+    alg = algorithmic_bytes_per_frame_decode(code.E, code.GF, nm, sweeps) * B
+    kavg = float(np.mean(kms)) * 1e-3
+    achieved = alg / kavg / 1e9
+    res = {
+        "value": round(world * B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "data": data,
+        "workload": "%s nm=%d NbIterMax=%d (%d sweeps) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, sweeps, off, nop),
+        "batch_per_gpu": B, "counters": tot, "counters_match_golden": match,
+        "roofline": {"bound": "hbm",
+                     "kernel": "%s (persistent, %s, %d waves per workgroup, %d frames per launch on %d CUs)"
+                               % (kernel, "1 wave per 2 frames" if "twin" in kernel else "1 workgroup per frame", wg_waves, B, n_cu),
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3),
+                     "llr_init_avg_ms": round(float(np.mean(lms)), 3)},
+        "host_setup_s": round(t_setup, 1), "oper": oper, "b256": b256,
+        "matrix": matrix, "params": (nm, nop, off, itmax, ebn),
+    }
+    # HBM bytes per launch from the PMC passes kept under profiles/ (scripts/pmc_passes.sh on an earlier box, same kernel):
+    # a committed measurement scaled to this batch, NOT a measurement of this run -- labelled as such
+    tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if os.path.exists(tr):
+        try:
+            tj = json.load(open(tr))
+            if tj["kernel"].split("::")[-1].split("(")[0] == kernel:
+                res["roofline"]["traffic"] = int(tj["hbm_bytes_per_frame"] * B)
+                res["roofline"]["traffic_source"] = ("profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at %d "
+                                                     "frames per launch, scaled per frame (committed measurement, not this run)" % (workload, tj["frames_per_launch"]))
+        except Exception:
+            pass
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="gf256", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-operational", action="store_true",
+                    help="skip the side measurements (early exit enabled, batch 256; SURVEY.md 8(d) 'operational' figure)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations reported under config.other_workloads")
+    ap.add_argument("--synthetic-zero-codeword", action="store_true",
+                    help="skip the host encoder: all-zero codeword + numpy AWGN (faster set-up, same work)")
+    a = ap.parse_args()
+
+    import torch  # first: its bundled libamdhip64 must be the one the decoder library binds to
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the decoder library has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1 or os.environ.get("EMS_BENCH_FORCE_DIST"):      # the env knob rehearses the RCCL path on one GPU
+        import torch.distributed as dist
+        with c_stdout_to_stderr():                  # RCCL prints its version banner on stdout when the communicator comes up
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        if dist.get_world_size() != a.gpus:         # a half-formed group would silently report a wrong aggregate
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (a.gpus, dist.get_world_size()))
+
+    pkg = ge.load_package()
+    if a.workload == "gf256_v2":
+        return bench_v2(a, pkg, ge, torch, dist, rank, world, local)
+    harness = importlib.import_module(ge.PKG_NAME + ".harness")
+    B = a.batch or WORKLOADS[a.workload][6]
+    main_res = run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, a.workload, B, a.steps, a.warmup,
+                                   side_figures=not a.no_operational)
+    # ---- the other BASELINE configurations (configs[1] and [2]) at their own batch, a few steps each: driver-timed side lines ----
+    others = {}
+    if a.workload == "gf256" and world == 1 and not a.no_other_workloads:
+        for w in ("gf16", "n96"):
+            r = run_decode_workload(a, pkg, harness, ge, torch, None, rank, 1, local, w, WORKLOADS[w][6], 5, 2, side_figures=False)
+            others[w] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": 5, "warmup": 2, "workload": r["workload"],
+                         "batch": r["batch_per_gpu"], "frames_errframes_biterrs_undetected_sumiter": r["counters"],
+                         "counters_match_golden": r["counters_match_golden"], "roofline": r["roofline"]}
     if rank == 0:
-        value = world * B * a.steps / dt
-        sweeps = itmax - 1
-        alg = algorithmic_bytes_per_frame_decode(code.E, code.GF, nm, sweeps) * B
-        kavg = float(np.mean(kms)) * 1e-3
-        achieved = alg / kavg / 1e9
+        nm, nop, off, itmax, ebn = main_res["params"]
         out = {
             "metric": "decoded frames/sec @ N=64800 GF(256) R=1/2, nm=20, 30 iters; 1/2/4/8 GPU" if a.workload == "gf256"
                       else "decoded frames/sec (%s)" % a.workload,
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": data,
-            "config": {"workload": "%s nm=%d NbIterMax=%d (%d sweeps) offset=%.1f NbOper=%d, fixed work (early exit off)"
-                                   % (mat, nm, itmax, sweeps, off, nop),
+            "value": main_res["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": main_res["data"],
+            "config": {"workload": main_res["workload"],
                        "batch_per_gpu": B, "sharding": "independent frames, contiguous batches per rank",
                        "collective": "all-reduce of 5 int64 error counters per step" if world > 1 else "none",
-                       "frames_errframes_biterrs_undetected_sumiter": tot},
-            "roofline": {"bound": "hbm", "kernel": "%s (persistent, %s, %d frames per launch)" % (kernel_name(a.workload, B), "1 wave per 2 frames" if kernel_name(a.workload, B) == "k_decode_twin" else "1 workgroup per frame", B),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3),
-                         "llr_init_avg_ms": round(float(np.mean(lms)), 3)},
-            "host_setup_s": round(t_setup, 1),
+                       "frames_errframes_biterrs_undetected_sumiter": main_res["counters"]},
+            # rank 0's counters of the timed run == the CPU oracle's on the same frames (tests/golden/bench_counters.json); null when
+            # the run is not the committed workload (other batch, --synthetic-zero-codeword, EMS_BENCH_EBN)
+            "counters_match_golden": main_res["counters_match_golden"],
+            "roofline": main_res["roofline"],
+            "host_setup_s": main_res["host_setup_s"],
         }
-        if a.workload == "gf256":
-            # beside the contract's peak: what the kernel's own access pattern (in-place 1 KiB row updates + 112-byte records) reaches on
-            # this part with no arithmetic at all -- build/row_traffic, profiles/r02_v3_row_traffic_probe.txt
-            out["roofline"]["access_pattern_ceiling"] = {"gbs": 4965.0, "frac": round(achieved / 4965.0, 5),
-                                                         "source": "csrc/probes/row_traffic.hip, profiles/r02_v3_row_traffic_probe.txt"}
-        if oper is not None:
-            out["config"]["operational_early_exit"] = oper
-        if b256 is not None:
-            out["config"]["batch256_fixed_work"] = b256
-        tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
-        if os.path.exists(tr):
-            try:
-                out["roofline"]["traffic"] = int(json.load(open(tr))["hbm_bytes_per_frame"] * B)   # measured per launch / frames
-            except Exception:
-                pass
+        if main_res["oper"] is not None:
+            out["config"]["operational_early_exit"] = main_res["oper"]
+        if main_res["b256"] is not None:
+            out["config"]["batch256_fixed_work"] = main_res["b256"]
+        if others:
+            out["config"]["other_workloads"] = others
         if world == 1 and not a.no_cpu_baseline:
             orc = ge.load_oracle()
             threads = max(1, min(os.cpu_count() or 1, 16))
-            out["cpu_baseline"] = cpu_baseline(orc, matrix, nm, nop, off, itmax, ebn, threads)
+            out["cpu_baseline"] = cpu_baseline(orc, main_res["matrix"], nm, nop, off, itmax, ebn, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

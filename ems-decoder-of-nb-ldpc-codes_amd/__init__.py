@@ -47,6 +47,11 @@ class Params(C.Structure):
                 ("early_exit", C.c_int)]
 
 
+class Tuning(C.Structure):
+    """ems_abi.h: ems_tuning -- launch-shape overrides, -1 = the library's choice."""
+    _fields_ = [("dual", C.c_int), ("waves", C.c_int), ("occ4", C.c_int), ("twin", C.c_int)]
+
+
 _lib = None
 
 
@@ -96,6 +101,13 @@ def lib():
         L.ems_check_node.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_int]
         L.ems_decision.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ems_syndrome.argtypes = [C.POINTER(CodeDesc), C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.ems_last_kernel_name.restype = C.c_char_p
+        L.ems_last_kernel_name.argtypes = [C.c_void_p]
+        L.ems_last_workgroup_waves.argtypes = [C.c_void_p]
+        L.ems_device_cu_count.argtypes = [C.c_void_p]
+        L.ems_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+        L.ems_get_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+        L.ems_suggest_batch.argtypes = [C.POINTER(CodeDesc), C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -145,6 +157,14 @@ def pair_schedule(code):
     buf = np.zeros(2 * code.M, np.int32)
     _check(lib().ems_pair_schedule(C.byref(code.desc), C.byref(n), _ptr(buf)))
     return buf[: 2 * n.value].reshape(-1, 2).copy()
+
+
+def suggest_batch(code, nm, nbOper, offset, NbIterMax, device=0, handles=1):
+    """Frames per launch that fill the device with the kernel the library picks for this code (ems_suggest_batch)."""
+    prm = Params(nm, nbOper, offset, NbIterMax, 1)
+    b = C.c_int(0)
+    _check(lib().ems_suggest_batch(C.byref(code.desc), C.byref(prm), device, handles, C.byref(b)))
+    return b.value
 
 
 def gf_tables(q):
@@ -336,6 +356,30 @@ class Decoder:
 
     def synchronize(self):
         _check(lib().ems_synchronize(self.h))
+
+    def set_tuning(self, dual=-1, waves=-1, occ4=0, twin=-1):
+        """Launch-shape overrides (ems_set_tuning); -1 = the library's choice."""
+        t = Tuning(dual, waves, occ4, twin)
+        _check(lib().ems_set_tuning(self.h, C.byref(t)))
+
+    @property
+    def tuning(self):
+        t = Tuning()
+        _check(lib().ems_get_tuning(self.h, C.byref(t)))
+        return dict(dual=t.dual, waves=t.waves, occ4=t.occ4, twin=t.twin)
+
+    @property
+    def last_kernel(self):
+        """Name of the decode kernel the last decode() / v2_decode() launched (template arguments included)."""
+        return lib().ems_last_kernel_name(self.h).decode()
+
+    @property
+    def last_workgroup_waves(self):
+        return int(lib().ems_last_workgroup_waves(self.h))
+
+    @property
+    def n_cu(self):
+        return int(lib().ems_device_cu_count(self.h))
 
     @property
     def last_decode_ms(self):

@@ -210,6 +210,12 @@ struct ems_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_llr_ev = false, have_dec_ev = false;
     EmsPlan plan{};
+    ems_tuning tune{-1, -1, 0, -1};     // launch-shape overrides (ems_set_tuning; initialised from EMS_DUAL / EMS_WAVES / EMS_OCC4 / EMS_TWIN at create)
+    bool pair_order = true;             // EMS_PAIR_ORDER=0 (create time): keep the pairs in discovery order
+    DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
+    int *fail_host = nullptr;           // pinned landing slot of its copy
+    std::string last_kernel;            // what the last ems_decode / ems_v2_decode launched
+    int last_waves = 0;
 };
 
 namespace {
@@ -251,7 +257,7 @@ void build_pairs(ems_handle *h)
     // re-ordered by a list-scheduling run on two waves with unit visit times: at every claim the ready pair (all
     // predecessors finished by then) that heads the longest remaining chain goes first; when none is ready, the one whose
     // predecessors finish soonest.  Any topological order gives the same bits; this one keeps the waves from waiting.
-    if (!getenv("EMS_PAIR_ORDER") || atoi(getenv("EMS_PAIR_ORDER")) != 0) {
+    if (h->pair_order) {
         std::vector<std::vector<int>> pp(NP), succ(NP);
         for (int i = 0; i < NP; ++i)
             for (int t : {pairs[i].first, pairs[i].second}) {
@@ -350,13 +356,14 @@ int refresh_plan(ems_handle *h)
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
     const int wcap = ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
-    if (const char *ew = getenv("EMS_WAVES")) waves = std::max(1, std::min(wcap, atoi(ew)));   // developer knob
+    if (h->tune.waves > 0) waves = std::max(1, std::min(wcap, h->tune.waves));                  // ems_set_tuning
     const size_t lds_cap = 160 * 1024;
     while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
     if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
     P.waves_per_wg = waves;
     P.occ4 = 0;
     P.stamps = h->d_stamps.p;
+    P.fail = h->d_fail.p;
     return EMS_OK;
 }
 
@@ -576,6 +583,8 @@ void ems_destroy(ems_handle *h)
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
+    h->d_fail.release();
+    if (h->fail_host) (void)hipHostFree(h->fail_host);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -593,6 +602,14 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     ems_handle *h = new ems_handle;
     h->device = device; h->max_batch = max_batch; h->nm_alloc = prm->nm; h->prm = *prm;
     (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    {   // developer variables, read here and nowhere else (ems_set_tuning is the API)
+        auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+        h->tune.dual = env_int("EMS_DUAL", -1);
+        h->tune.waves = env_int("EMS_WAVES", -1);
+        h->tune.occ4 = getenv("EMS_OCC4") ? 1 : 0;
+        h->tune.twin = env_int("EMS_TWIN", -1);
+        h->pair_order = env_int("EMS_PAIR_ORDER", 1) != 0;
+    }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);
     auto bail = [&](int code) { ems_destroy(h); return code; };
@@ -636,8 +653,11 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
-        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)))
+        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)))
         return bail(r);
+    if (hipMemset(h->d_fail.p, 0, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&h->fail_host, sizeof(int), hipHostMallocDefault) != hipSuccess)
+        return bail(fail(EMS_EHIP, "allocation of the failure word failed"));
+    *h->fail_host = 0;
     if ((r = refresh_plan(h))) return bail(r);
     *out = h;
     return EMS_OK;
@@ -658,6 +678,18 @@ static int check_batch(ems_handle *h, int B)
     if (!h) return fail(EMS_EINVAL, "null handle");
     if (B < 1 || B > h->max_batch) return fail(EMS_EINVAL, "batch %d outside [1, %d]", B, h->max_batch);
     HIP_TRY(hipSetDevice(h->device));
+    return EMS_OK;
+}
+
+// Wait for the handle's stream.  The decode kernels set the handle's failure word (and store iters = -1) for a frame whose
+// dependency wait gave up -- a bounded spin that never trips unless the schedule is broken: such a frame ran on
+// unsynchronised inputs, so from then on every waiting entry point of the handle refuses its results.  The word rides the
+// handle's own stream into pinned memory (nothing touches the null stream).
+static int sync_and_check(ems_handle *h)
+{
+    HIP_TRY(hipMemcpyAsync(h->fail_host, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (*h->fail_host) return fail(EMS_EHIP, "a check-node visit gave up waiting for its predecessors (results of this handle are invalid)");
     return EMS_OK;
 }
 
@@ -745,36 +777,38 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
         while (waves > 1 && ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, waves) > lds_cap) --waves;
         return waves;
     };
-    // developer knobs: EMS_DUAL=<waves per workgroup> forces the two-visits-per-wave kernel, EMS_DUAL=0 forbids it
-    const char *ed = getenv("EMS_DUAL");
-    if (allow_dual && ed && atoi(ed) > 0 && ems_has_dual_kernel(P)) { go_dual(dual_fit(atoi(ed))); return; }
-    if (getenv("EMS_WAVES")) { P.occ4 = getenv("EMS_OCC4") ? 1 : 0; return; }
+    // overrides (ems_set_tuning): dual = <waves per workgroup> forces the two-visits-per-wave kernel, dual = 0 forbids it (and the
+    // two-frames-per-wave kernel with it); waves = <n> forces the one-visit kernel in n-wave workgroups
+    const int td = h->tune.dual;
+    const bool no_dual = td == 0;
+    if (allow_dual && td > 0 && ems_has_dual_kernel(P)) { go_dual(dual_fit(td)); return; }
+    if (h->tune.waves > 0) { P.occ4 = h->tune.occ4 ? 1 : 0; return; }
     // dc = 8 (the GF(16) configuration): the elementary steps are most of a visit, so the dual kernel is used at every
     // batch size, with the workgroup the one-visit kernel would have had
-    if (allow_dual && !(ed && atoi(ed) == 0) && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }
+    if (allow_dual && !no_dual && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }
     // a code whose levels hold a handful of check nodes (the N = 96 bits GF(64) code: 8 check nodes, levels of 1-3) keeps a workgroup of
     // one wave busy at best: one wave walking the pairs in order, two visits at a time (measured 1.72e6 against 1.42e6 frames/s)
     {   // ... and where pairing inside one frame leaves slots empty (that code: six pair slots for eight check nodes), one wave takes two
-        // FRAMES instead and walks the check nodes in reference order (k_decode_twin).  EMS_TWIN=1 forces it at any batch, EMS_TWIN=0 forbids it.
-        const char *et = getenv("EMS_TWIN");
+        // FRAMES instead and walks the check nodes in reference order (k_decode_twin).  tuning.twin = 1 forces it at any batch, 0 forbids it.
+        const int tt = h->tune.twin;
         const bool sparse_pairs = P.n_pairs > 0 && 10 * P.n_pairs > 6 * h->M;          // more than a fifth of the slots would be empty
-        if (allow_dual && ems_has_twin_kernel(P) && !(ed && atoi(ed) > 0) &&
-            (et ? atoi(et) > 0 : (sparse_pairs && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu))) {
+        if (allow_dual && ems_has_twin_kernel(P) && td < 0 &&
+            (tt >= 0 ? tt > 0 : (sparse_pairs && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu))) {
             P.twin = 1; P.waves_per_wg = 1; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
             return;
         }
     }
-    if (allow_dual && !(ed && atoi(ed) == 0) && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu && ems_has_dual_kernel(P)) { go_dual(1); return; }
+    if (allow_dual && !no_dual && P.waves_per_wg <= 4 && h->n_cu > 0 && B >= 4 * h->n_cu && ems_has_dual_kernel(P)) { go_dual(1); return; }
     if (ems_lpe_for(h->dc) != 16 || P.waves_per_wg < 12 || h->n_cu <= 0) return;   // (the batch shapes below belong to the dc <= 4 kernels)
     const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
-    if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 5 && ems_has_dual_kernel(P) &&
+    if (allow_dual && !no_dual && fpc >= 5 && ems_has_dual_kernel(P) &&
         6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 2 KiB units: 27 KiB workgroups ran five to a CU, 13 KiB ones eleven)
     // two or three frames per CU: the same kernel in 4-wave workgroups, three to a CU (measured on the headline code, frames/s at
     // batch 512 / 768: 2811 / 3636 against 2403 / 2922 for the one-visit shapes; at 256 the 12-wave one-visit workgroup wins,
     // 2391 against 1559, and at 1024 its 128-VGPR 4-wave build, 3295 against 2964)
-    if (allow_dual && !(ed && atoi(ed) == 0) && fpc >= 2 && fpc <= 3 && ems_has_dual_kernel(P) &&
+    if (allow_dual && !no_dual && fpc >= 2 && fpc <= 3 && ems_has_dual_kernel(P) &&
         3 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 4) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(4); return; }
     if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
     else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
@@ -787,7 +821,10 @@ int ems_decode(ems_handle *h, int B)
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     EmsPlan P = h->plan;
     shape_for_batch(h, B, P);
-    HIP_TRY(ems_launch_decode(P, B, h->stream));
+    const char *kn = "";
+    HIP_TRY(ems_launch_decode(P, B, h->stream, &kn));
+    h->last_kernel = kn;
+    h->last_waves = P.waves_per_wg;
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->have_dec_ev = true;
     return EMS_OK;
@@ -802,19 +839,8 @@ int ems_get_results(ems_handle *h, int B, int *decide, int *iters, int *synd)
     if (decide) HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_decide.p, tmp.size(), hipMemcpyDeviceToHost, h->stream));
     if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     if (synd) HIP_TRY(hipMemcpyAsync(synd, h->d_synd.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((r = sync_and_check(h))) return r;
     for (size_t i = 0; i < tmp.size(); ++i) decide[i] = tmp[i];
-    // The decode kernels store iters = -1 for a frame whose dependency wait gave up (a bounded spin that never
-    // trips unless the schedule is broken): such a frame ran on unsynchronised inputs, so the batch is refused.
-    std::vector<int> it_chk;
-    const int *itp = iters;
-    if (!itp) {
-        it_chk.resize((size_t)B);
-        HIP_TRY(hipMemcpy(it_chk.data(), h->d_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
-        itp = it_chk.data();
-    }
-    for (int b = 0; b < B; ++b)
-        if (itp[b] < 0) return fail(EMS_EHIP, "frame %d: a check-node visit gave up waiting for its predecessors (results invalid)", b);
     return EMS_OK;
 }
 
@@ -834,8 +860,7 @@ int ems_count_errors(ems_handle *h, const int *cw_host, int B, int *nb_errors)
     HIP_TRY(hipMemcpyAsync(h->d_cw.p, cw_host, sizeof(int) * (size_t)B * h->N, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(ems_launch_count_errors(h->d_decide.p, h->d_cw.p, B, h->N, h->K, h->d_i2b.p, h->d_nberr.p, h->stream));
     HIP_TRY(hipMemcpyAsync(nb_errors, h->d_nberr.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return EMS_OK;
+    return sync_and_check(h);
 }
 
 
@@ -928,7 +953,7 @@ int ems_count_errors_resident(ems_handle *h, int B, int *nb_errors)
     HIP_TRY(ems_launch_count_errors(h->d_decide.p, h->d_cw.p, B, h->N, h->K, h->d_i2b.p, h->d_nberr.p, h->stream));
     if (nb_errors) {
         HIP_TRY(hipMemcpyAsync(nb_errors, h->d_nberr.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        return sync_and_check(h);
     }
     return EMS_OK;
 }
@@ -1138,14 +1163,14 @@ int ems_v2_decode(ems_handle *h, int B)
     shape_for_batch(h, B, P, false);                                    // 4-wave workgroups, 3 frames per CU, for big batches
     P.p_dst = h->d_v2_p_dst.n ? h->d_v2_p_dst.p : nullptr; P.p_last = h->d_v2_p_last.n ? h->d_v2_p_last.p : nullptr;
     {   // five or more frames per CU: the two-visits-per-wave kernel (2-wave workgroups, six to a CU), as the main path
-        const char *ed = getenv("EMS_DUAL");
+        const int td = h->tune.dual;
         const long fpc = h->n_cu > 0 ? ((long)B + h->n_cu - 1) / h->n_cu : 0;
         // two or three frames per CU: 4-wave workgroups of it, three to a CU (measured at batch 512 / 768: 2418 / 3112 frames/s
         // against 1843 / 2319 for the one-visit shapes; at 1024 the one-visit 4-wave shape wins, 2617 against 2439)
         const bool mid = fpc >= 2 && fpc <= 3;
-        const bool want = ed ? atoi(ed) > 0 : (fpc >= 5 || mid);
-        const int wv = ed && atoi(ed) > 0 ? std::min(4, atoi(ed)) : (mid ? 4 : 2);
-        if (want && !getenv("EMS_WAVES") && ems_has_v2_dual_kernel(P) &&
+        const bool want = td >= 0 ? td > 0 : (fpc >= 5 || mid);
+        const int wv = td > 0 ? std::min(4, td) : (mid ? 4 : 2);
+        if (want && h->tune.waves <= 0 && ems_has_v2_dual_kernel(P) &&
             (wv == 4 ? 3 : 6) * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, wv == 4 ? 4 : 2) + 2047) & ~(size_t)2047) <= (size_t)160 * 1024) {
             P.dual = 1; P.occ4 = 0;
             P.waves_per_wg = wv;
@@ -1156,7 +1181,10 @@ int ems_v2_decode(ems_handle *h, int B)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
     P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-    HIP_TRY(ems_launch_decode_v2(P, B, h->stream));
+    const char *kn = "";
+    HIP_TRY(ems_launch_decode_v2(P, B, h->stream, &kn));
+    h->last_kernel = kn;
+    h->last_waves = P.waves_per_wg;
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->have_dec_ev = true;
     return EMS_OK;
@@ -1279,7 +1307,54 @@ int ems_synchronize(ems_handle *h)
 {
     if (!h) return fail(EMS_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    return sync_and_check(h);
+}
+
+const char *ems_last_kernel_name(const ems_handle *h) { return h ? h->last_kernel.c_str() : ""; }
+int ems_last_workgroup_waves(const ems_handle *h) { return h ? h->last_waves : 0; }
+int ems_device_cu_count(const ems_handle *h) { return h ? h->n_cu : 0; }
+
+// Frames per launch that fill the device with the kernel shape_for_batch would pick (see there for the measurements behind
+// the frames-per-CU figures), within the free HBM for `handles` handles.
+int ems_suggest_batch(const ems_code_desc *c, const ems_params *prm, int device, int handles, int *batch)
+{
+    if (!c || !prm || !batch || !c->rowDegree || c->N <= 0 || c->M <= 0 || handles < 1) return fail(EMS_EINVAL, "bad argument");
+    int r = select_device(device);
+    if (r) return r;
+    int n_cu = 0;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (n_cu <= 0) n_cu = 256;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const int dc = c->rowDegree[0], q = c->GF, logq = ilog2(q);
+    EmsPlan P{};
+    P.q = q; P.dc = dc; P.nm = prm->nm; P.nbOper = prm->nbOper; P.M = c->M; P.n_pairs = 1;
+    // per-frame state of one handle: APP rows, C->V records, decisions, noisy samples, codewords, counters
+    const size_t per_frame = (size_t)c->N * q * 4 + (size_t)c->nbBranch * ems_rec_bytes(prm->nm) + (size_t)c->N * (1 + 4 * logq + 4) + 16;
+    long fpc;
+    if (per_frame < (1u << 20)) fpc = 32;                         // short codes: state lives in the caches, waves are what they want (N = 96: 8192 frames)
+    else if (ems_has_dual_kernel(P)) fpc = dc == 8 ? 1 : 6;       // GF(16) dc 8: flat from 256 to 2048 frames; GF(256) dc 4: six 2-wave workgroups per CU
+    else fpc = ems_lpe_for(dc) == 16 ? 3 : 1;                     // one-visit kernels: three 4-wave workgroups per CU (dc <= 4), else one workgroup per CU
+    long b = fpc * n_cu;
+    const size_t budget = free_b / 10 * 8 / (size_t)handles;
+    if ((size_t)b * per_frame > budget) b = (long)(budget / per_frame);
+    if (b >= n_cu) b -= b % n_cu;                                 // whole frames-per-CU steps
+    *batch = (int)std::max<long>(1, b);
+    return EMS_OK;
+}
+
+int ems_set_tuning(ems_handle *h, const ems_tuning *t)
+{
+    if (!h || !t) return fail(EMS_EINVAL, "null argument");
+    if (t->dual > 16 || t->waves > 16) return fail(EMS_EINVAL, "at most 16 waves per workgroup");
+    h->tune = *t;
+    return refresh_plan(h);
+}
+
+int ems_get_tuning(const ems_handle *h, ems_tuning *t)
+{
+    if (!h || !t) return fail(EMS_EINVAL, "null argument");
+    *t = h->tune;
     return EMS_OK;
 }
 

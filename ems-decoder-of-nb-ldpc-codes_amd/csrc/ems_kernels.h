@@ -19,12 +19,13 @@ size_t ems_dual_wave_lds_bytes(int q, int dc, int nm);
 size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves);
 hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
                               float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st);
-hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st);
+hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st, const char **kname = nullptr);
 hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, float *vtoc, uint8_t *vtoci,
                                    float *hint, int *bad, hipStream_t st);
 hipError_t ems_launch_sort_like_desc(const float *likeS, int N, int q, float *s_like, int *s_idx, hipStream_t st);
 
-hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st);
+// kname (optional) receives the launched kernel's name, template arguments included: a static string
+hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st, const char **kname = nullptr);
 hipError_t ems_launch_llr_init(const float *noisy_dev, float sigma, int logq, int q, size_t total,
                                const uint8_t *idx2bin_dev, const uint8_t *bin2idx_dev, float *app_dev, hipStream_t st);
 hipError_t ems_launch_llr_const(const float *obs_dev, const float *att_dev, const float *table_dev, int q, int D, int mode, float sigma,

@@ -1450,6 +1450,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) 
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
+        if (*spin_fail && P.fail) atomicOr(P.fail, 1);           // sticky per handle: every waiting entry point reports it
     }
 }
 
@@ -1630,6 +1631,7 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? (Q == 64 ? EMS
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
+        if (*spin_fail && P.fail) atomicOr(P.fail, 1);           // sticky per handle: every waiting entry point reports it
     }
 }
 
@@ -2208,6 +2210,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
+        if (*spin_fail && P.fail) atomicOr(P.fail, 1);           // sticky per handle: every waiting entry point reports it
     }
 }
 
@@ -2325,6 +2328,7 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
     if (tid == 0) {
         P.iters[f] = *spin_fail ? -1 : it;
         P.synd[f] = (int)synd;
+        if (*spin_fail && P.fail) atomicOr(P.fail, 1);           // sticky per handle: every waiting entry point reports it
     }
 }
 
@@ -2763,8 +2767,18 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
 
+// name of a kernel instantiation as rocprofv3 prints it (without the argument list)
+static const char *kname_fmt(const char *fmt, int a, int b, int c = 0, int d = 0, int e = 0)
+{
+    static thread_local char buf[96];
+    snprintf(buf, sizeof buf, fmt, a, b, c, d, e);
+    return buf;
+}
+static thread_local const char *g_kname = "";
+
 template <int Q, int LPE, int DC = 0, int NM = 0, bool OCC4 = false> static hipError_t launch_decode_t(const EmsPlan &P, int B, hipStream_t st)
 {
+    g_kname = kname_fmt(OCC4 ? "k_decode<%d, %d, %d, %d, true>" : "k_decode<%d, %d, %d, %d, false>", Q, LPE, DC, NM);
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
     hipError_t e = set_max_lds(k_decode<Q, LPE, DC, NM, OCC4>, lds);
     if (e != hipSuccess) return e;
@@ -2783,6 +2797,7 @@ size_t ems_dual_wave_lds_bytes(int q, int dc, int nm) { return (size_t)dual_wave
 size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, dc, n_pairs) + (size_t)dual_wave_bytes(q, dc, nm) * waves; }
 template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
 {
+    g_kname = kname_fmt("k_decode_dual<%d, %d, %d>", Q, NM, DC);
     const size_t lds = ems_dual_wg_lds_bytes(Q, DC, P.nm, P.n_pairs, P.waves_per_wg);
     hipError_t e = set_max_lds(k_decode_dual<Q, NM, DC>, lds);
     if (e != hipSuccess) return e;
@@ -2794,6 +2809,7 @@ bool ems_has_twin_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 64 && P
 size_t ems_twin_wg_lds_bytes(int q, int dc, int nm) { return (size_t)dual_header_bytes(q, dc, 0) + (size_t)dual_wave_bytes(q, dc, nm); }
 template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const EmsPlan &P, int B, hipStream_t st)
 {
+    g_kname = kname_fmt("k_decode_twin<%d, %d, %d>", Q, NM, DC);
     const size_t lds = ems_twin_wg_lds_bytes(Q, DC, NM);
     hipError_t e = set_max_lds(k_decode_twin<Q, NM, DC>, lds);
     if (e != hipSuccess) return e;
@@ -2803,7 +2819,15 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const Em
 // kernels that also exist in the 16-waves-per-CU build
 bool ems_has_occ4_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == 4 && P.nm == 20; }
 
-hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st)
+static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st);
+hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st, const char **kname)
+{
+    g_kname = "";
+    const hipError_t e = launch_decode_any(P, B, st);
+    if (kname) *kname = g_kname;
+    return e;
+}
+static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
 {
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
@@ -2962,6 +2986,7 @@ hipError_t ems_launch_sort_like_desc(const float *likeS, int N, int q, float *s_
 }
 template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launch_decode_v2_t(const EmsPlan &P, int B, hipStream_t st)
 {
+    g_kname = kname_fmt(OCC4 ? "k_decode_v2<%d, %d, %d, true>" : "k_decode_v2<%d, %d, %d, false>", Q, LPE, NM);
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
     hipError_t e = set_max_lds(k_decode_v2<Q, LPE, NM, OCC4>, lds);
     if (e != hipSuccess) return e;
@@ -2969,11 +2994,20 @@ template <int Q, int LPE, int NM = 0, bool OCC4 = false> static hipError_t launc
     return hipGetLastError();
 }
 bool ems_has_v2_dual_kernel(const EmsPlan &P) { return P.q == 256 && P.dc == 4 && P.nm == 20 && P.nbOper >= 23 && P.nbOper <= 64 && P.n_pairs > 0 && P.p_dst; }
-hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st)
+static hipError_t launch_decode_v2_any(const EmsPlan &P0, int B, hipStream_t st);
+hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st, const char **kname)
+{
+    g_kname = "";
+    const hipError_t e = launch_decode_v2_any(P0, B, st);
+    if (kname) *kname = g_kname;
+    return e;
+}
+static hipError_t launch_decode_v2_any(const EmsPlan &P0, int B, hipStream_t st)
 {
     if (P0.dual) {
         if (!ems_has_v2_dual_kernel(P0) || P0.waves_per_wg > 4 || P0.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P0.q, P0.dc, P0.nm)) return hipErrorInvalidValue;
         const size_t lds = ems_dual_wg_lds_bytes(P0.q, P0.dc, P0.nm, P0.n_pairs, P0.waves_per_wg);
+        g_kname = "k_decode_v2_dual<256, 20>";
         hipError_t e = set_max_lds(k_decode_v2_dual<256, 20>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_decode_v2_dual<256, 20>), dim3(B), dim3(P0.waves_per_wg * 64), lds, st, P0);

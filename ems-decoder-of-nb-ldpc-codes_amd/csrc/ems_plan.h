@@ -68,6 +68,7 @@ struct EmsPlan {
     uint8_t *decide;        // [B][N]
     int *iters;             // [B]
     int *synd;              // [B]
+    int *fail;              // one word per handle: set (never cleared by a kernel) when a dependency wait gave up, see ems_get_results
     int rec_bytes;
     int wave_lds_bytes;     // LDS per wave
     int waves_per_wg;

@@ -5,7 +5,7 @@
  * frame, never reseeded), same progress line, same 40-erroneous-frame stop and same result-file line as
  * the reference's main() (NB_LDPC.c:63-604).  The only structural change is the one north_star asks
  * for: the inline per-frame decode block (NB_LDPC.c:266-472) is replaced by one batched call into the
- * GPU library -- frames are generated EMS_BATCH at a time (default 1536, env EMS_BATCH) by EMS_THREADS host
+ * GPU library -- frames are generated EMS_BATCH at a time (default: what fills the device, ems_suggest_batch) by EMS_THREADS host
  * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
  * Several decoder handles (EMS_INFLIGHT, default 3) take turns so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
@@ -89,10 +89,7 @@ int main(int argc, char *argv[])
     const int nbMax = atoi(argv[5]);
     const float offset = (float)atof(argv[6]);
     const int NbOper = atoi(argv[7]);
-    /* default batch: 1536 frames = 6 per CU of an MI355X, the shape that runs the two-visits-per-wave kernel */
-    int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 1536;
-    if (batch > NbMonteCarlo) batch = NbMonteCarlo;            /* (no buffers for frames that are never drawn) */
-    if (batch < 1) batch = 1;
+    int batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 0;   /* 0: derived from the device once the code is loaded (ems_suggest_batch) */
     const int device = getenv("EMS_DEVICE") ? atoi(getenv("EMS_DEVICE")) : 0;
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int threads = getenv("EMS_THREADS") ? atoi(getenv("EMS_THREADS")) : (int)(ncpu > 16 ? 16 : (ncpu < 1 ? 1 : ncpu));
@@ -141,6 +138,14 @@ int main(int argc, char *argv[])
     if (NH > NH_MAX) NH = NH_MAX;
     ems_handle *hd[NH_MAX] = {NULL, NULL, NULL, NULL};
     int rc;
+    const int batch_given = batch > 0;
+    /* default batch: the frames that fill this device with the kernel the library picks for this code (e.g. 6 per CU for the
+     * GF(256) dc = 4 codes), within the free HBM for NH handles */
+    if (!batch_given && (rc = ems_suggest_batch(&desc, &prm, device, NH, &batch))) die("ems_suggest_batch", rc);
+    if (batch > NbMonteCarlo) batch = NbMonteCarlo;            /* (no buffers for frames that are never drawn) */
+    if (batch < 1) batch = 1;
+    fprintf(stderr, "[ems_sim] batch %d frames per launch (%s), %d handle(s) in flight, device %d\n", batch,
+            batch_given ? "EMS_BATCH" : "derived from the device", NH, device);
     for (int i = 0; i < NH; i++)
         if ((rc = ems_create(&hd[i], &desc, &prm, batch, device))) die("ems_create", rc);
     if (gpu_source)

@@ -189,11 +189,33 @@ int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *
 int ems_decision(int GF, int N, const float *app /*[N][GF]*/, int *decide, int device);
 int ems_syndrome(const ems_code_desc *code, const int *decide, int *synd, int device);
 
+/* ---- launch shape ----
+ * The library picks the decode kernel and its workgroup shape from the code, the message size and the batch
+ * (DESIGN.md 4.1).  A harness that wants another one says so HERE, once, not through the environment of every call:
+ * each field is -1 for "the library's choice".  ems_create initialises the handle's tuning from the developer variables
+ * EMS_DUAL / EMS_WAVES / EMS_OCC4 / EMS_TWIN (read once, at create); the hot entry points never call getenv.
+ *   dual   0 = never the two-visits-per-wave kernels (nor two frames per wave); n > 0 = force them, n waves per workgroup
+ *   waves  n > 0 = force the one-visit kernel with n waves per workgroup (occ4 != 0: its 128-VGPR build)
+ *   twin   0 = never two FRAMES per wave (tiny codes); 1 = force it */
+typedef struct { int dual, waves, occ4, twin; } ems_tuning;
+int ems_set_tuning(ems_handle *h, const ems_tuning *t);
+int ems_get_tuning(const ems_handle *h, ems_tuning *t);
+/* Frames per launch that fill device `device` for this code and message size with the kernel the library would pick
+ * (n_CU x the tuned frames per CU of that kernel), capped so that `handles` decoder handles of that size fit the
+ * free HBM.  What ems_sim uses when EMS_BATCH is not given. */
+int ems_suggest_batch(const ems_code_desc *code, const ems_params *prm, int device, int handles, int *batch);
+
 /* ---- measurement ---- */
 /* Duration in ms of the kernels of the last ems_llr_init / ems_decode call, from HIP events recorded
  * on the handle's own stream around the launches. */
 float ems_last_llr_ms(const ems_handle *h);
 float ems_last_decode_ms(const ems_handle *h);
+/* The decode kernel the last ems_decode / ems_v2_decode launched, as the profiler names it without its argument list
+ * (e.g. "k_decode_dual<256, 20, 4>"), its workgroup size in waves, and the device's compute-unit count: what a bench
+ * reports instead of restating the library's shape rule.  "" / 0 before the first decode. */
+const char *ems_last_kernel_name(const ems_handle *h);
+int ems_last_workgroup_waves(const ems_handle *h);
+int ems_device_cu_count(const ems_handle *h);
 /* Raw device access for zero-copy drivers (bench.py): device pointer of the noisy-sample staging
  * buffer [max_batch][N][logGF] float and the handle's stream (hipStream_t as void*). */
 void *ems_noisy_dev_ptr(ems_handle *h);

@@ -14,6 +14,13 @@
  * The GPU-backed symbols return after the device work has completed and fail loudly (message on
  * stderr, non-zero status where the signature has one) when no HIP device is usable; none of them
  * falls back to a CPU implementation.
+ *
+ * This layer is a COMPATIBILITY SHIM, not the fast path: the reference's loop hands over one frame at a time, so
+ * Decoding() is a batch of ONE on a decoder context the library keeps per code_t (one global table under a mutex,
+ * created on first use, destroyed by FreeCode) -- about 105 ms per frame of the 64800-bit GF(256) code, the latency of a
+ * frame's 441-level dependency chain, with the other 255 compute units idle.  It exists so that the reference's own main()
+ * runs unchanged (oracle/Makefile builds NB_LDPC.c against it: oracle/_ref/essai_gpu); throughput needs the batched handle
+ * API of ems_abi.h, which ems_sim.c shows.
  */
 #ifndef NBLDPC_REF_API_H
 #define NBLDPC_REF_API_H
@@ -22,7 +29,11 @@
 extern "C" {
 #endif
 
-/* ---- types: layout-identical to struct.h:48-108 ---- */
+/* ---- types: layout-identical to struct.h:48-108 (oracle/abi_layout_check.c asserts it at compile time against the reference's
+ *      own header).  A translation unit that already has the reference's struct.h defines NBLDPC_REF_HAVE_STRUCT_H and gets the
+ *      prototypes below declared on the reference's types (oracle/abi_proto_check.c: the compiler then checks every signature
+ *      against init.h / tools.h / channel.h / bubble_decoder.h). ---- */
+#ifndef NBLDPC_REF_HAVE_STRUCT_H
 typedef float softdata_t; /* struct.h:82 */
 
 typedef struct {          /* struct.h:48-64 */
@@ -61,6 +72,7 @@ typedef struct {          /* struct.h:88-108 */
     softdata_t **M_CtoV_LLR;     /* [rowDegree[0]][GF] */
     int **M_CtoV_GF;
 } decoder_t;
+#endif /* NBLDPC_REF_HAVE_STRUCT_H */
 
 /* ---- init.h:11-29 (host) ---- */
 void Table_Add_GF(table_t *table, int GF, int logGF);          /* init.h:11 */

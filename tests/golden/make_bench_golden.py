@@ -1,0 +1,71 @@
+"""Generates tests/golden/bench_golden.npz + bench_counters.json: what the CPU oracle (oracle/ems_oracle.c, pinned against the
+real reference by tests/test_oracle_vs_reference.py) gives on the EXACT workloads bench.py times --
+
+    gf256  Ahmed_64800_R12_GF256  nm 20 NbOper 40 offset 0.3 NbIterMax 30, 1.0 dB, fixed work, frames 0..1535 of the drand48 stream
+    gf16   Ahmed_64800_R34_GF16   nm 8  NbOper 16 offset 0.3 NbIterMax 30, 0.0 dB, fixed work, frames 0..255
+    n96    N96_K48_GF64           nm 16 NbOper 32 offset 0.3 NbIterMax 30, -3.0 dB, fixed work, frames 0..8191
+
+(BASELINE.json configs[3] / [2] / [1] at the batch the bench runs them).  Per frame: bit errors over the first K symbols
+(NB_LDPC.c:479-485), the value Syndrom returns, CRC-32 of the hard decisions (as bytes) and CRC-32 of the whole APP block
+after the last sweep; per workload the five counters of the harness (frames, erroneous frames, bit errors, undetected,
+sum of iterations; NB_LDPC.c:474-497) that bench.py compares its timed run with (`counters_match_golden`).
+
+    python tests/golden/make_bench_golden.py [gf256] [gf16] [n96]     (run from the repo root; gf256 takes ~15 min on 8 cores)
+"""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+
+WORKLOADS = {   # name: (matrix, nm, NbOper, offset, NbIterMax, Eb/N0, frames) -- bench.py's WORKLOADS
+    "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1536),
+    "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
+    "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
+}
+
+
+def generate(name, threads):
+    mat, nm, nop, off, itmax, ebn, F = WORKLOADS[name]
+    o = orc.Oracle(os.path.join(ROOT, "tests", "golden", "matrices", mat))
+    sigma = o.sigma(ebn)
+    rng = orc.Rng(0)
+    frames = [o.draw_frame(rng, sigma) for _ in range(F)]          # the reference's stream, frame after frame (NB_LDPC.c:255-261)
+
+    def one(i):
+        cw, noisy = frames[i]
+        r = o.decode(o.llr(noisy, sigma), nm, nop, off, itmax, early_exit=False, want_state=True)
+        return (o.bit_errors(r["decide"], cw), r["synd"], r["iters"], orc.crc32(r["decide"].astype(np.uint8)), orc.crc32(r["app"]))
+
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        rec = np.array(list(ex.map(one, range(F))), dtype=np.int64)
+    nerr, synd, iters = rec[:, 0], rec[:, 1], rec[:, 2]
+    counters = [F, int((nerr != 0).sum()), int(nerr.sum()), int(((nerr != 0) & (synd == 0)).sum()), int(iters.sum())]
+    print("%s: %d frames in %.0f s; counters %s" % (name, F, time.time() - t0, counters), flush=True)
+    return rec, counters
+
+
+if __name__ == "__main__":
+    orc.build()
+    which = sys.argv[1:] or list(WORKLOADS)
+    threads = int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count() or 8)))
+    gdir = os.path.join(ROOT, "tests", "golden")
+    npz = os.path.join(gdir, "bench_golden.npz")
+    cj = os.path.join(gdir, "bench_counters.json")
+    arrays = dict(np.load(npz)) if os.path.exists(npz) else {}
+    counters = json.load(open(cj)) if os.path.exists(cj) else {}
+    for name in which:
+        rec, cnt = generate(name, threads)
+        mat, nm, nop, off, itmax, ebn, F = WORKLOADS[name]
+        arrays[name] = rec.astype(np.int64)         # columns: bit errors, syndrome, iterations, CRC-32(decisions as u8), CRC-32(APP)
+        counters[name] = {"matrix": mat, "nm": nm, "NbOper": nop, "offset": off, "NbIterMax": itmax, "EbN": ebn, "batch": F,
+                          "first_frame": 0, "frames_errframes_biterrs_undetected_sumiter": cnt}
+        np.savez_compressed(npz, **arrays)
+        json.dump(counters, open(cj, "w"), indent=1)

@@ -1,0 +1,64 @@
+"""The drop-in boundary against the reference's OWN translation unit and headers.
+
+CPU part (-m "not gpu"): `make -C oracle abi_check` compiles oracle/abi_layout_check.c (sizeof / offsetof / field types of code_t,
+table_t, decoder_t in include/nbldpc_ref_api.h == the reference's include/struct.h:48-108) and oracle/abi_proto_check.c (every
+prototype both sides declare, in one translation unit); and oracle/_ref/essai_gpu -- the reference's NB_LDPC.c with its inline
+decode block replaced by Decoding(), compiled against the reference's headers -- links: every symbol it imports is exported by
+libems_hip.so.  GPU part (-m gpu): that executable prints the traces the unmodified reference printed (tests/golden/kat_traces.json)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import MAT, ROOT
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+ESSAI_GPU = os.path.join(REF_DIR, "essai_gpu")
+HAVE_REF_TREE = os.path.exists("/root/reference/include/struct.h")
+
+
+@pytest.mark.skipif(not HAVE_REF_TREE, reason="needs the reference's headers under /root/reference (absent on the GPU box)")
+def test_struct_layouts_and_prototypes_match_the_reference_headers():
+    for obj in ("abi_layout_check.o", "abi_proto_check.o"):           # force a fresh compile: compiling IS the test
+        p = os.path.join(REF_DIR, obj)
+        if os.path.exists(p):
+            os.remove(p)
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "abi_check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    assert os.path.exists(os.path.join(REF_DIR, "abi_layout_check.o")) and os.path.exists(os.path.join(REF_DIR, "abi_proto_check.o"))
+
+
+def _dynamic_symbols(path, undefined):
+    out = subprocess.run(["nm", "-D", "--undefined-only" if undefined else "--defined-only", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    return {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+
+
+def test_reference_main_links_against_the_library(pkg):
+    if not os.path.exists(ESSAI_GPU):
+        pytest.skip("oracle/_ref/essai_gpu is not built (make -C oracle ref, needs /root/reference)")
+    wanted = {s for s in _dynamic_symbols(ESSAI_GPU, True) if not s.startswith("_") and s[0].isupper()}   # the reference's CamelCase API
+    assert {"LoadCode", "LoadTables", "AllocateDecoder", "GaussianElimination", "RandomBinaryGenerator", "Encoding",
+            "ModelChannel_AWGN_BPSK", "Decoding", "FreeCode", "FreeDecoder", "FreeTable"} <= wanted
+    assert wanted <= _dynamic_symbols(pkg.LIB_PATH, False)
+
+
+def _run(exe, args, cwd):
+    os.makedirs(os.path.join(cwd, "data"), exist_ok=True)
+    out = subprocess.run([exe] + [str(a) for a in args], cwd=cwd, input=b"\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
+            re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", out.stdout.decode("latin-1"))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K4", "K5"])
+def test_reference_main_on_the_gpu_library_prints_the_reference_traces(kat, tmp_path, name):
+    """NB_LDPC.c's own main() -- argv parsing, LoadCode ... ModelChannel_AWGN_BPSK, BER/FER counting, progress line, 40-error stop --
+    driving libems_hip.so through Decoding(): the trace of the unmodified reference executable, frame for frame."""
+    if not os.path.exists(ESSAI_GPU):
+        pytest.skip("oracle/_ref/essai_gpu is not built (make -C oracle ref, needs /root/reference)")
+    k = kat[name]
+    matrix = {"N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])     # (the library's loader detects the layout itself)
+    tr = _run(ESSAI_GPU, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]], str(tmp_path))
+    assert tr == [list(t) for t in k["trace"]]
