@@ -577,6 +577,169 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     if (has && p16 == 0) lens[o_id] = S;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ElementaryStep over GF(16) with nm = 8 (BASELINE configs[2]), "first occurrence per symbol" form.
+//
+// The bubble loop of bubble_decoder.c:472-562 walks the 8 nm - 16 = 48 cells of the L-shaped region in the order of
+// (value, competitor, position) -- every competitor's list is non-decreasing, so the 8-way merge is that sort -- and its output is
+// the first nm DISTINCT symbols met, each with the value of its first occurrence, cut by the stops.  With 16 symbols the
+// scan can be replaced by one LDS ds_min per cell into a 16-entry table (bin s = smallest value of a cell with symbol s =
+// the first occurrence of s), a rank of the 16 bins, and three closed-form tests for the stops:
+//   * a source index of -1 (:478): such a cell's value is >= 1e5 under the visit's guard, it sorts behind every valid cell, so
+//     cells >= 1e5 simply do not exist;
+//   * last row / column (:506): the scan ends after the cheapest boundary cell (row 7 or column 7), value K; a symbol is
+//     emitted iff its bin is <= K;
+//   * nm outputs (:502): the first 8 bins in rank order;
+//   * nbOper (:472): the scan up to the last emitted entry (or K) visits N = #{cells <= that value} cells; if N > nbOper the
+//     reference stops early -- such a task (0.2 % of them at NbOper = 16) is redone by the merge form;
+// and so is a task where the order of two equal values could matter: two bins with the same value (their ranks then do not
+// add up), or a second cell with the value K when the scan gets that far.  Equal values with the same symbol, and ties among
+// cells that are not first occurrences, change nothing.  Values are compared as floats by the sign of their difference
+// (non-negative, no NaN among valid ones) or as bit patterns.
+// TL = 8 lanes per task (lane = competitor: its fixed entry and the 8 cells of its row, or the 4 of its column) or 16 (three
+// cells per lane, one bin per lane).  bins: 16 words per task, all +inf on entry and on exit.  Returns true on the lanes of a
+// task that must be redone by es_stage_fast.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned Q16_INF = 0x7F800000u;
+constexpr unsigned Q16_LIM = 0x47C34FFFu;                  // largest float below 1e5f (0x47C35000)
+
+template <int TL> __device__ __forceinline__ int redT_sumi(int x)
+{
+    x = red8_sumi(x);
+    if (TL == 16) x += dpp_i<DPP_MIRROR>(x);
+    return x;
+}
+template <int TL> __device__ __forceinline__ unsigned redT_minu(unsigned x)
+{
+    x = red8_minu(x);
+    if (TL == 16) x = min(x, (unsigned)dpp_i<DPP_MIRROR>((int)x));
+    return x;
+}
+template <int TL> __device__ __forceinline__ unsigned redT_maxu(unsigned x)
+{
+    x = max(x, (unsigned)dpp_i<DPP_XOR1>((int)x));
+    x = max(x, (unsigned)dpp_i<DPP_XOR2>((int)x));
+    x = max(x, (unsigned)dpp_i<DPP_HMIRROR>((int)x));
+    if (TL == 16) x = max(x, (unsigned)dpp_i<DPP_MIRROR>((int)x));
+    return x;
+}
+// number of elements of x[0..N) that are > T (floats, T >= 0 finite, x may hold +inf): sign bits of T - x
+template <int N> __device__ __forceinline__ int count_above(const float (&x)[N], float T)
+{
+    unsigned a = 0u;
+#pragma unroll
+    for (int e = 0; e < N; ++e) a = __builtin_amdgcn_alignbit(a, __float_as_uint(T - x[e]), 31);
+    return __popc(a);
+}
+
+template <int TL>
+__device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigned *bins_base, int lane, uint2 task, int nbOper)
+{
+    constexpr int NS = TL == 8 ? 8 : 3;                    // cells per lane
+    constexpr int NB = 16 / TL;                            // bins per lane
+    const int p = lane & (TL - 1);
+    const int gsel = lane / TL;
+    const bool has = (task.y >> 16) != 0u;
+    const int o_id = (int)(task.y >> 16) - 1;
+    uint8_t *lb = reinterpret_cast<uint8_t *>(lists);
+    const EmsEntry *in1 = reinterpret_cast<const EmsEntry *>(lb + (task.x & 0xFFFFu));
+    const EmsEntry *in2 = reinterpret_cast<const EmsEntry *>(lb + (task.x >> 16));
+    EmsEntry *out = reinterpret_cast<EmsEntry *>(lb + (task.y & 0xFFFFu));
+    unsigned *bins = bins_base + gsel * 16;
+
+    float v[NS];
+    unsigned sy[NS];
+    float bnd;                                             // this lane's boundary cell (row 7 / column 7), +inf when it has none
+    if constexpr (TL == 8) {
+        // competitor p < 4: row p, cells (p, 0..7); p >= 4: column p - 4, cells (4..7, p - 4) in slots 4..7 -- slot 7 is the boundary cell
+        const bool rowc = p < 4;
+        const EmsEntry fx = rowc ? in1[p] : in2[p - 4];
+        const uint4 *mv4 = reinterpret_cast<const uint4 *>(rowc ? in2 : in1);
+        const uint4 e01 = mv4[0], e23 = mv4[1], e45 = mv4[2], e67 = mv4[3];
+        const unsigned ev[8] = {e01.x, e01.z, e23.x, e23.z, e45.x, e45.z, e67.x, e67.z};
+        const unsigned es[8] = {e01.y, e01.w, e23.y, e23.w, e45.y, e45.w, e67.y, e67.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = fx.v + __uint_as_float(ev[j]);          // tab_aux[r][c] = In1[r] + In2[c] (:386-423)
+            sy[j] = (fx.s ^ es[j]) & 15u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rowc ? v[j] : __builtin_inff();   // a column competitor starts on row 4
+        bnd = v[7];
+    } else {
+        // cell i = p + 16 k: k = 0, 1 -> (row (p >> 3) + 2 k, column p & 7); k = 2 -> (row 4 + (p >> 2), column p & 3)
+        const int r0 = p >> 3, c0 = p & 7, r2 = 4 + (p >> 2), c2 = p & 3;
+        const EmsEntry a0 = in1[r0], a1 = in1[r0 + 2], b0 = in2[c0], a2 = in1[r2], b2 = in2[c2];
+        v[0] = a0.v + b0.v; sy[0] = (a0.s ^ b0.s) & 15u;
+        v[1] = a1.v + b0.v; sy[1] = (a1.s ^ b0.s) & 15u;
+        v[2] = a2.v + b2.v; sy[2] = (a2.s ^ b2.s) & 15u;
+        bnd = c0 == 7 ? fminf(v[0], v[1]) : __builtin_inff();
+        bnd = r2 == 7 ? fminf(bnd, v[2]) : bnd;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) atomicMin(&bins[sy[j]], __float_as_uint(v[j]));   // (cells >= 1e5 land above every valid value: harmless)
+    const unsigned kstop = redT_minu<TL>(__float_as_uint(bnd));                   // :506, value of the cell that ends the scan
+    const unsigned klim = min(kstop, Q16_LIM);
+    wave_lds_sync();
+
+    // ---- rank of the 16 first occurrences ----
+    const uint4 *b4 = reinterpret_cast<const uint4 *>(bins);
+    const uint4 q0 = b4[0], q1 = b4[1], q2 = b4[2], q3 = b4[3];
+    const float all[16] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w),
+                           __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w),
+                           __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w),
+                           __uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z), __uint_as_float(q3.w)};
+    unsigned mine[NB];
+    if constexpr (NB == 2) {
+        const uint2 m2 = *reinterpret_cast<const uint2 *>(bins + 2 * p);
+        mine[0] = m2.x; mine[1] = m2.y;
+    } else {
+        mine[0] = bins[p];
+    }
+    int rank[NB];
+    bool valid[NB];
+    int nvalid = 0, rsum = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float me = __uint_as_float(mine[k]);
+        unsigned a = 0u;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a = __builtin_amdgcn_alignbit(a, __float_as_uint(all[t] - me), 31);   // sign: all[t] < me
+        rank[k] = __popc(a);
+        valid[k] = mine[k] <= klim;
+        nvalid += valid[k] ? 1 : 0;
+        rsum += valid[k] ? rank[k] : 0;
+    }
+    const int D = redT_sumi<TL>(nvalid);
+    rsum = redT_sumi<TL>(rsum);
+    bool bad = 2 * rsum != D * (D - 1);                    // two first occurrences with the same value: their order is the competitors'
+    const int S = min(D, 8);
+    unsigned x7 = 0u;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (has && valid[k] && rank[k] < 8) out[rank[k]] = EmsEntry{__uint_as_float(mine[k]), (unsigned)(NB * p + k)};   // :492-494
+        x7 = (valid[k] && rank[k] == 7) ? mine[k] : x7;
+    }
+    // ---- the stops that depend on how far the scan got ----
+    const unsigned xcut = D >= 8 ? redT_maxu<TL>(x7) : klim;                      // value of the last cell the scan visits
+    const int N = redT_sumi<TL>(NS - count_above(v, __uint_as_float(xcut)));      // cells visited until then
+    bad = bad || N > nbOper;                                                     // :472 would have cut the scan short
+    int eq = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) eq += (__float_as_uint(v[j]) == kstop) ? 1 : 0;
+    eq = redT_sumi<TL>(eq);
+    bad = bad || (kstop <= xcut && eq > 1);                                      // another cell with the value that ends the scan
+    // ---- tail, pads, length; bins back to +inf ----
+    if (has) {
+        if (p < 8 && p >= S) out[p] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID};     // :370-374 shows through behind the S entries
+        if (p < 2) out[8 + p] = EmsEntry{__builtin_inff(), EMS_S_INVALID};
+        if (p == 0) lens[o_id] = S;
+    }
+    if constexpr (NB == 2) *reinterpret_cast<uint2 *>(bins + 2 * p) = uint2{Q16_INF, Q16_INF};
+    else bins[p] = Q16_INF;
+    return has && bad;
+}
+
 // Decoder parameters as the device functions see them.  In the specialised kernel instantiations
 // (template DC, NM > 0) dc, nm and the first-pass length T1 are compile-time constants after inlining, so
 // the small loops over list entries unroll and most of the scalar bookkeeping folds away.
@@ -660,15 +823,24 @@ __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int
 }
 
 // TL lanes per elementary-step task: 16 (one visit per wave; the literal form uses 8 of them twice over) or 8 (two visits)
+// bins: the 16-word-per-task tables of es_stage_q16 (all +inf), or null: GF(16) / nm = 8 visits then take the first-occurrence form
 template <int TL = 16>
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
-                                        int lane, bool literal ST_PARAMS)
+                                        int lane, bool literal, unsigned *bins ST_PARAMS)
 {
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
+    const bool q16 = fast && bins != nullptr && C.q == 16 && C.nm == 8;
     for (int t = 1; t <= C.nsteps; ++t) {
         const bool wide = TL == 8 && dual_stage_wide(C.dc, t);      // (two-visit waves: see dual_stage_wide)
         const int grp = wide ? lane / 16 : lane / TL;
         const uint2 task = sched[(t - 1) * 8 + grp];
+        if (q16) {
+            STAMP(8);
+            const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
+            STAMP(9);
+            if (__ballot(redo) == 0ull) { wave_lds_sync(); continue; }
+            wave_lds_sync();                                        // (rare) some task of the stage needs the exact merge: the whole stage again
+        }
         if (fast && wide) es_stage_fast<16>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else {
@@ -1220,11 +1392,20 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     // tables of the elementary steps, zeroed here and kept all-zero from stage to stage
     unsigned *tbl = reinterpret_cast<unsigned *>(dense);
     for (int i = lane * 4; i < (DUAL ? 8 : 4) * Q; i += 256) *reinterpret_cast<uint4 *>(tbl + i) = uint4{0u, 0u, 0u, 0u};
+    // GF(16): the staging area is twice the dedupe tables (2 dc rows of 16 words against 8 or 4 tables of 16): its second half holds
+    // the first-occurrence tables of es_stage_q16, one per task, all +inf
+    unsigned *bins = nullptr;
+#ifndef EMS_NO_Q16
+    if constexpr (Q == 16 && G::NROWS * Q >= 2 * (DUAL ? 8 : 4) * Q) {
+        bins = tbl + (DUAL ? 8 : 4) * Q;
+        for (int i = lane * 4; i < (DUAL ? 8 : 4) * 16; i += 256) *reinterpret_cast<uint4 *>(bins + i) = uint4{Q16_INF, Q16_INF, Q16_INF, Q16_INF};
+    }
+#endif
     wave_lds_sync();
 #if defined(EMS_ABL) && (EMS_ABL == 1 || EMS_ABL == 5)      // ablation builds (make ablation; timing experiments, results wrong by construction): no elementary steps, the output list of an edge is its input list
-    (void)tbl;
+    (void)tbl; (void)bins;
 #else
-    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull ST_ARGS);
+    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull, bins ST_ARGS);
 #endif
 
     STAMP(2);
@@ -2653,10 +2834,12 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     __shared__ __attribute__((aligned(16))) unsigned tbl[4 * 256];
     __shared__ uint8_t picks[ES_PICK_BYTES];
     __shared__ uint2 sched[CN_SCHED_BYTES / 8];
+    __shared__ __attribute__((aligned(16))) unsigned bins[4 * 16];           // es_stage_q16's tables (GF(16), nm = 8)
     const int lane = threadIdx.x;
     bool big = false;
     cn_sched_build(sched, dc, nm, lane, 64);
     for (int i = lane; i < 4 * 256; i += 64) tbl[i] = 0u;
+    bins[lane] = Q16_INF;
     for (int i = lane; i < dc * nmp; i += 64) {                // rotation, bubble_decoder.c:133-152
         const int t = i / nmp, k = i - t * nmp;
         if (k >= nm) {
@@ -2673,7 +2856,7 @@ __global__ void k_cn_unit(const EmsPlan P, const int *coef, const float *vtoc_ll
     C.dc = dc; C.nm = nm; C.nbOper = P.nbOper; C.T1 = min(P.nbOper, nm + 3); C.q = Q; C.nsteps = dc - 2;
     C.n_lists = P.n_lists; C.offset = P.offset;
     ST_DUMMY
-    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull ST_ARGS);
+    cn_core(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull, Q == 16 ? bins : nullptr ST_ARGS);
     for (int t = 0; t < dc; ++t) {                             // bubble_decoder.c:231-278
         const int oid = P.out_list[t];
         const EmsEntry *ol = lists + oid * nmp;

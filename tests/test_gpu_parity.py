@@ -56,6 +56,38 @@ def test_check_node_random_vs_oracle(pkg, orc, q, nm, dc):
         assert pkg.CheckPassLogEMS(coef, vl, vg, q, nop, 0.3).tobytes() == o.check_node(coef, vl, vg, nop, 0.3).tobytes()
 
 
+@pytest.mark.parametrize("dc", [8, 5, 12])
+def test_check_node_gf16_first_occurrence_form_vs_oracle(pkg, orc, dc):
+    """GF(16) with nm = 8 takes the closed form of the elementary step (es_stage_q16: one LDS minimum per cell into a table of 16
+    symbols, a rank of the 16 first occurrences, closed-form stop tests) and redoes a stage by the merge form when a tie or the
+    NbOper limit could matter.  Continuous values (no ties: the closed form decides alone), coarse ones (ties everywhere: the
+    redo path), NbOper from nm (the limit binds) to 3 nm, lists with -1 tails -- dense C->V rows against the oracle, bit for bit."""
+    q, nm = 16, 8
+    o = FieldOracle(orc, q)
+    rs = np.random.RandomState(100 + dc)
+    for it in range(120):
+        vl = np.zeros((dc, nm), np.float32)
+        vg = np.zeros((dc, nm), np.int32)
+        for t in range(dc):
+            if it % 3 == 0:
+                x = rs.uniform(0.0, 12.0, nm)                          # continuous
+            elif it % 3 == 1:
+                x = rs.randint(0, 24, nm) * 0.5                        # massive ties
+            else:
+                x = np.round(rs.uniform(0.0, 6.0, nm), 1)              # a few ties
+            vl[t] = np.sort(x.astype(np.float32))
+            vl[t, 0] = 0
+            vg[t] = rs.permutation(q)[:nm]
+            if it % 7 == 3 and t % 2:                                  # a short list: (1e5, -1) behind its valid entries
+                k = int(rs.randint(5, nm))
+                vl[t, k:] = 1e5
+                vg[t, k:] = -1
+        coef = rs.randint(1, q, dc).astype(np.int32)
+        nop = int(rs.choice([nm, nm + 3, 2 * nm, 3 * nm]))
+        got = pkg.CheckPassLogEMS(coef, vl, vg, q, nop, 0.3)
+        assert got.tobytes() == o.check_node(coef, vl, vg, nop, 0.3).tobytes(), (dc, it, nop)
+
+
 def test_decision_and_syndrome_units(pkg, orc):
     path = os.path.join(MAT, "Ahmed_64800_R34_GF16")
     o = orc.Oracle(path)
