@@ -24,6 +24,10 @@
 
 #include "ems_kernels.h"
 
+#ifndef EMS_Q16_RELANE
+#define EMS_Q16_RELANE 0     // 1: the GF(16) two-visit kernel re-derives its lane geometry per phase too (see RELANE in process_cn); measured slower
+#endif
+
 namespace {
 
 // Diagnostic build only (-DEMS_STAMPS): per-phase shader-cycle totals of the check-node visits,
@@ -626,9 +630,17 @@ template <int TL> __device__ __forceinline__ unsigned redT_maxu(unsigned x)
 // number of elements of x[0..N) that are > T (floats, T >= 0 finite, x may hold +inf): sign bits of T - x
 template <int N> __device__ __forceinline__ int count_above(const float (&x)[N], float T)
 {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f t2 = {T, T};
     unsigned a = 0u;
+    int e = 0;
 #pragma unroll
-    for (int e = 0; e < N; ++e) a = __builtin_amdgcn_alignbit(a, __float_as_uint(T - x[e]), 31);
+    for (; e + 1 < N; e += 2) {                            // two differences per v_pk_add_f32
+        const v2f d = t2 - v2f{x[e], x[e + 1]};
+        a = __builtin_amdgcn_alignbit(a, __float_as_uint(d.x), 31);
+        a = __builtin_amdgcn_alignbit(a, __float_as_uint(d.y), 31);
+    }
+    if (e < N) a = __builtin_amdgcn_alignbit(a, __float_as_uint(T - x[e]), 31);
     return __popc(a);
 }
 
@@ -654,7 +666,7 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
         // competitor p < 4: row p, cells (p, 0..7); p >= 4: column p - 4, cells (4..7, p - 4) in slots 4..7 -- slot 7 is the boundary cell
         const bool rowc = p < 4;
         const EmsEntry fx = rowc ? in1[p] : in2[p - 4];
-        const uint4 *mv4 = reinterpret_cast<const uint4 *>(rowc ? in2 : in1);
+        const uint4 *mv4 = static_cast<const uint4 *>(__builtin_assume_aligned(rowc ? in2 : in1, 16));   // (lists are 80 bytes apart from a 16-byte-aligned base)
         const uint4 e01 = mv4[0], e23 = mv4[1], e45 = mv4[2], e67 = mv4[3];
         const unsigned ev[8] = {e01.x, e01.z, e23.x, e23.z, e45.x, e45.z, e67.x, e67.z};
         const unsigned es[8] = {e01.y, e01.w, e23.y, e23.w, e45.y, e45.w, e67.y, e67.w};
@@ -683,12 +695,9 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     wave_lds_sync();
 
     // ---- rank of the 16 first occurrences ----
-    const uint4 *b4 = reinterpret_cast<const uint4 *>(bins);
-    const uint4 q0 = b4[0], q1 = b4[1], q2 = b4[2], q3 = b4[3];
-    const float all[16] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w),
-                           __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w),
-                           __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w),
-                           __uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z), __uint_as_float(q3.w)};
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *b4 = static_cast<const v4f *>(__builtin_assume_aligned(bins, 64));
     unsigned mine[NB];
     if constexpr (NB == 2) {
         const uint2 m2 = *reinterpret_cast<const uint2 *>(bins + 2 * p);
@@ -696,22 +705,42 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     } else {
         mine[0] = bins[p];
     }
+    unsigned acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                          // four bins per LDS read, two differences per v_pk_add_f32
+        const v4f q = b4[c];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const float me = __uint_as_float(mine[k]);
+            const v2f m2 = {me, me};
+            const v2f dl = v2f{q.x, q.y} - m2, dh = v2f{q.z, q.w} - m2;                 // sign: that bin < mine
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dl.x), 31);
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dl.y), 31);
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dh.x), 31);
+            acc[k] = __builtin_amdgcn_alignbit(acc[k], __float_as_uint(dh.y), 31);
+        }
+    }
+    // Five small counts travel through ONE butterfly: valid bins (bits 0-4), the sum of their ranks (5-12), valid bins whose value is
+    // the one that ends the scan (13-17), boundary cells with that value (23-27) and, of those, the ones that are the first
+    // occurrence of their symbol (18-22).
     int rank[NB];
     bool valid[NB];
-    int nvalid = 0, rsum = 0;
+    int pack = 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const float me = __uint_as_float(mine[k]);
-        unsigned a = 0u;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) a = __builtin_amdgcn_alignbit(a, __float_as_uint(all[t] - me), 31);   // sign: all[t] < me
-        rank[k] = __popc(a);
+        rank[k] = __popc(acc[k]);
         valid[k] = mine[k] <= klim;
-        nvalid += valid[k] ? 1 : 0;
-        rsum += valid[k] ? rank[k] : 0;
+        pack += valid[k] ? 1 + (rank[k] << 5) : 0;
+        if constexpr (TL == 8) pack += (valid[k] && mine[k] == kstop) ? (1 << 13) : 0;
     }
-    const int D = redT_sumi<TL>(nvalid);
-    rsum = redT_sumi<TL>(rsum);
+    if constexpr (TL == 8) {
+        const bool is_b = __float_as_uint(bnd) == kstop && kstop <= Q16_LIM;
+        pack += is_b ? (1 << 23) + (bins[sy[7]] == kstop ? (1 << 18) : 0) : 0;
+    }
+    pack = redT_sumi<TL>(pack);
+    const int D = pack & 31, rsum = (pack >> 5) & 255;
     bool bad = 2 * rsum != D * (D - 1);                    // two first occurrences with the same value: their order is the competitors'
     const int S = min(D, 8);
     unsigned x7 = 0u;
@@ -722,13 +751,20 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     }
     // ---- the stops that depend on how far the scan got ----
     const unsigned xcut = D >= 8 ? redT_maxu<TL>(x7) : klim;                      // value of the last cell the scan visits
-    const int N = redT_sumi<TL>(NS - count_above(v, __uint_as_float(xcut)));      // cells visited until then
-    bad = bad || N > nbOper;                                                     // :472 would have cut the scan short
-    int eq = 0;
+    int cnt = NS - count_above(v, __uint_as_float(xcut));                        // cells visited until then (bits 0-7)
+    if constexpr (TL == 16) {                                                    // ... and cells with the value that ends the scan (8-15)
 #pragma unroll
-    for (int j = 0; j < NS; ++j) eq += (__float_as_uint(v[j]) == kstop) ? 1 : 0;
-    eq = redT_sumi<TL>(eq);
-    bad = bad || (kstop <= xcut && eq > 1);                                      // another cell with the value that ends the scan
+        for (int j = 0; j < NS; ++j) cnt += (__float_as_uint(v[j]) == kstop) ? 256 : 0;
+    }
+    cnt = redT_sumi<TL>(cnt);
+    bad = bad || (cnt & 255) > nbOper;                                           // :472 would have cut the scan short
+    // Another cell with the value K that ends the scan, when the scan gets that far: the order of the two would matter.  Rows of 16
+    // lanes count the cells with that value.  Rows of 8 read it off the bins: a tie matters only when the other cell is the first
+    // occurrence of ANOTHER symbol (a repeated symbol changes nothing, the same symbol gives the same entry either way) -- then its
+    // bin holds K; if the boundary cell is a first occurrence too, two bins hold K and the rank sum above has already failed, so what
+    // is left is "some valid bin holds K and no boundary cell at K is a first occurrence", plus two boundary cells at K.
+    if constexpr (TL == 16) bad = bad || (kstop <= xcut && (cnt >> 8) > 1);
+    else bad = bad || (kstop <= xcut && (((pack >> 23) & 31) > 1 || (((pack >> 13) & 31) >= 1 && ((pack >> 18) & 31) == 0)));
     // ---- tail, pads, length; bins back to +inf ----
     if (has) {
         if (p < 8 && p >= S) out[p] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID};     // :370-374 shows through behind the S entries
@@ -830,10 +866,21 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
 {
     const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
     const bool q16 = fast && bins != nullptr && C.q == 16 && C.nm == 8;
-    for (int t = 1; t <= C.nsteps; ++t) {
+    auto task_of = [&](int t) {
         const bool wide = TL == 8 && dual_stage_wide(C.dc, t);      // (two-visit waves: see dual_stage_wide)
-        const int grp = wide ? lane / 16 : lane / TL;
-        const uint2 task = sched[(t - 1) * 8 + grp];
+        return sched[(t - 1) * 8 + (wide ? lane / 16 : lane / TL)];
+    };
+#ifdef EMS_TASK_PREFETCH
+    uint2 task_next = task_of(1);
+#endif
+    for (int t = 1; t <= C.nsteps; ++t) {
+        const bool wide = TL == 8 && dual_stage_wide(C.dc, t);
+#ifdef EMS_TASK_PREFETCH
+        const uint2 task = task_next;
+        if (t < C.nsteps) task_next = task_of(t + 1);               // the next stage's task travels under this stage
+#else
+        const uint2 task = task_of(t);
+#endif
         if (q16) {
             STAMP(8);
             const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
@@ -1288,7 +1335,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     // lane id -- the compiler otherwise keeps some eighty such values (LDS addresses, lane masks, literals) in VGPRs across the whole
     // kernel loop; re-deriving them costs ~2 % in instructions and brings these kernels under 128 VGPRs = 4 waves per SIMD.
 #ifndef EMS_NO_RELANE
-    constexpr bool RELANE = DUAL && Q == 64;
+    constexpr bool RELANE = DUAL && (Q == 64 || (Q == 16 && EMS_Q16_RELANE));
 #else
     constexpr bool RELANE = false;
 #endif
@@ -1662,10 +1709,13 @@ __host__ __device__ inline int dual_wave_bytes(int q, int dc, int nm)
 #ifndef EMS_Q64_BLOCKS
 #define EMS_Q64_BLOCKS 4
 #endif
+#ifndef EMS_DC8_WAVES
+#define EMS_DC8_WAVES 16     // waves per workgroup of the dc = 8 build (16: 128 VGPRs, 12: 168)
+#endif
 // DC = 4 (GF(256) headline): at most four waves per workgroup, 168 VGPRs for three waves per SIMD (GF(64): 128 for four, see RELANE).
 // DC = 8 (GF(16), 4 symbols per lane): up to 16 waves per workgroup.
 template <int Q, int NM, int DC>
-__global__ void __launch_bounds__(DC == 4 ? 256 : 1024, DC == 4 ? (Q == 64 ? EMS_Q64_BLOCKS : 3) : 1) k_decode_dual(const EmsPlan P)
+__global__ void __launch_bounds__(DC == 4 ? 256 : EMS_DC8_WAVES * 64, DC == 4 ? (Q == 64 ? EMS_Q64_BLOCKS : 3) : 1) k_decode_dual(const EmsPlan P)
 {
     constexpr int LPE = 32 / DC;
     constexpr int DUAL_DC = DC, DUAL_NLISTS = dual_nlists(DC), DUAL_SCHED_BYTES = dual_sched_bytes(DC);
@@ -2975,7 +3025,7 @@ bool ems_has_dual_kernel(const EmsPlan &P)
     return spec_ok(P) && P.n_pairs > 0 &&
            ((P.q == 256 && P.dc == 4 && P.nm == 20) || (P.q == 16 && P.dc == 8 && P.nm == 8) || (P.q == 64 && P.dc == 4 && (P.nm == 16 || P.nm == 24)));   // (nm = 24: the reference's own test description, NB_LDPC.c:48-60)
 }
-int ems_dual_max_waves(int dc) { return dc == 4 ? 4 : 16; }
+int ems_dual_max_waves(int dc) { return dc == 4 ? 4 : EMS_DC8_WAVES; }
 size_t ems_dual_wave_lds_bytes(int q, int dc, int nm) { return (size_t)dual_wave_bytes(q, dc, nm); }
 size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, dc, n_pairs) + (size_t)dual_wave_bytes(q, dc, nm) * waves; }
 template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
