@@ -885,7 +885,9 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
             STAMP(8);
             const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
             STAMP(9);
+            DBG_ADD(3, 1);
             if (__ballot(redo) == 0ull) { wave_lds_sync(); continue; }
+            DBG_ADD(5, 1);
             wave_lds_sync();                                        // (rare) some task of the stage needs the exact merge: the whole stage again
         }
         if (fast && wide) es_stage_fast<16>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);

@@ -12,6 +12,13 @@
  * the frame source to the device-side counter-based generator (ems_source_draw): no host generation at all,
  * statistical instead of bit parity with the reference's frames.
  *
+ * EMS_DEVICES=0,1,...,7 runs ONE simulation on several GPUs of the node (run_multi below, ems_multi.h): one host thread per
+ * device, batch j of the stream on device j mod D, and per round one RCCL all-reduce (ncclAllReduce, ncclInt64, ncclSum) of the
+ * five counters {frames, erroneous frames, bit errors, undetected, sum of iterations} over xGMI -- the only collective of the
+ * path -- on which every device takes the same "40 erroneous frames" stop; the per-frame results stay on the host and device 0's
+ * thread prints the reference's progress line in frame order, cut at exactly the 40th erroneous frame.  EMS_DEVICES=0 runs the
+ * same code, collective included, on one GPU.
+ *
  *   ems_sim NbMonteCarlo NbIterMax FileMatrix EbN NbMax Offset NbOper
  */
 #include <math.h>
@@ -22,7 +29,11 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>            /* (plain C: device selection, the 40-byte staging copies and the stream of the all-reduce) */
+
 #include "ems_abi.h"
+#include "ems_multi.h"
 #include "nbldpc_ref_api.h"
 
 static void die(const char *what, int rc)
@@ -64,6 +75,212 @@ static void *generate(void *arg)
     clock_gettime(CLOCK_MONOTONIC, &g1);
     j->seconds = (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);
     return NULL;
+}
+
+/* the end of the reference's main() (NB_LDPC.c:563-583): result-file line and closing messages */
+static void report(const char *file_name, float EbN, int nbErroneousFrames, int nb_logged, int total_errors, long long sum_it, int K, int logGF)
+{
+    printf(" \n results are printed in file %s \n", file_name);
+    time_t now = time(NULL);
+    char *ts = ctime(&now);
+    FILE *op = fopen(file_name, "a");
+    if (!op) {
+        printf(" \n !! file not found \n ");
+    } else {
+        fprintf(op, " SNR:%.2f: \t FER= %d / %d = %f ", EbN, nbErroneousFrames, nb_logged, (double)nbErroneousFrames / nb_logged);
+        fprintf(op, " \t BER= %d / x = \t %f  avr_it= \t %.2f \t time: %s", total_errors,
+                (double)total_errors / ((double)nb_logged * K * logGF), (double)sum_it / nb_logged, ts);
+        fclose(op);
+    }
+    printf(" \n results printed \n ");
+    printf("\n");
+    printf("Simulation complete at time: %s", ts);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * several GPUs, one simulation (EMS_DEVICES)
+ * ---------------------------------------------------------------------------------------------------------------------- */
+/* RCCL is a 570 MB library: it is loaded only when EMS_DEVICES asks for it.  Prototypes as in rccl.h:236 / :260 / :339 / :611. */
+typedef struct {
+    void *lib;
+    int (*CommInitAll)(void **comm, int ndev, const int *devlist);
+    int (*AllReduce)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op, void *comm, hipStream_t stream);
+    int (*CommDestroy)(void *comm);
+    const char *(*GetErrorString)(int result);
+} rccl_api;
+enum { RCCL_INT64 = 4 /* ncclInt64, rccl.h:463 */, RCCL_SUM = 0 /* ncclSum, rccl.h:448 */ };
+
+static int rccl_load(rccl_api *r)
+{
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", NULL};
+    r->lib = NULL;
+    for (int i = 0; names[i] && !r->lib; i++) r->lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!r->lib) { fprintf(stderr, "cannot load RCCL: %s\n", dlerror()); return -1; }
+    *(void **)&r->CommInitAll = dlsym(r->lib, "ncclCommInitAll");
+    *(void **)&r->AllReduce = dlsym(r->lib, "ncclAllReduce");
+    *(void **)&r->CommDestroy = dlsym(r->lib, "ncclCommDestroy");
+    *(void **)&r->GetErrorString = dlsym(r->lib, "ncclGetErrorString");
+    if (!r->CommInitAll || !r->AllReduce || !r->CommDestroy || !r->GetErrorString) { fprintf(stderr, "RCCL: symbols missing\n"); return -1; }
+    return 0;
+}
+
+typedef struct {
+    int hip_dev;                            /* device ordinal */
+    ems_handle *h[2];                       /* two batches in flight per device (ems_multi.h) */
+    int *cw[2];
+    float *noisy[2];
+    long long first[2];
+    int *iters, *synd, *nberr;
+    void *comm;                             /* ncclComm_t */
+    hipStream_t cstream;                    /* the all-reduce's own stream */
+    long long *d_cnt;                       /* [2][5] send | receive */
+} dev_ctx;
+
+typedef struct {
+    dev_ctx *d;
+    int ndev, threads_per_dev, gpu_source, K, logGF;
+    code_t *code;
+    table_t *table;
+    float EbN, sigma_dev;
+    unsigned long long gpu_seed;
+    long long first_frame;
+    rccl_api nccl;
+} multi_ctx;
+
+static int m_launch(void *c, int dev, int slot, long long first, int count)
+{
+    multi_ctx *m = (multi_ctx *)c;
+    dev_ctx *d = &m->d[dev];
+    int rc;
+    d->first[slot] = first;
+    if (m->gpu_source) {
+        if ((rc = ems_source_draw(d->h[slot], m->gpu_seed, (unsigned long long)(m->first_frame + first), count, m->sigma_dev))) goto bad;
+    } else {
+        float sigma = 0.0f;                 /* the reference's stream from any frame on (LCG jump-ahead), frame-parallel on this device's share of the cores */
+        if (ems_draw_frames(m->code, m->table, (long)(m->first_frame + first), count, m->EbN, m->threads_per_dev, d->cw[slot], d->noisy[slot], &sigma)) {
+            fprintf(stderr, "\nems_draw_frames failed\n");
+            return -1;
+        }
+        if ((rc = ems_llr_init(d->h[slot], d->noisy[slot], sigma, count))) goto bad;
+    }
+    if ((rc = ems_decode(d->h[slot], count))) goto bad;
+    return 0;
+bad:
+    fprintf(stderr, "\ndevice %d: launch failed (%d): %s\n", d->hip_dev, rc, ems_last_error());
+    return -1;
+}
+
+static int m_collect(void *c, int dev, int slot, int count, ems_frame_result *res)
+{
+    multi_ctx *m = (multi_ctx *)c;
+    dev_ctx *d = &m->d[dev];
+    int rc;
+    if (!res) return ems_synchronize(d->h[slot]) ? -1 : 0;           /* launched ahead of the stop: dropped */
+    if ((rc = ems_get_results(d->h[slot], count, NULL, d->iters, d->synd)) ||
+        (rc = m->gpu_source ? ems_count_errors_resident(d->h[slot], count, d->nberr) : ems_count_errors(d->h[slot], d->cw[slot], count, d->nberr))) {
+        fprintf(stderr, "\ndevice %d: collect failed (%d): %s\n", d->hip_dev, rc, ems_last_error());
+        return -1;
+    }
+    for (int b = 0; b < count; b++) {
+        res[b].nberr = d->nberr[b]; res[b].synd = d->synd[b]; res[b].iters = d->iters[b];
+    }
+    return 0;
+}
+
+/* the path's one collective: ncclAllReduce(5 x int64, sum) on the device's own communicator and stream */
+static int m_allreduce(void *c, int dev, long long v[EMS_NCOUNTERS])
+{
+    multi_ctx *m = (multi_ctx *)c;
+    dev_ctx *d = &m->d[dev];
+    int nrc;
+    if (hipSetDevice(d->hip_dev) != hipSuccess ||
+        hipMemcpyAsync(d->d_cnt, v, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyHostToDevice, d->cstream) != hipSuccess) return -1;
+    if ((nrc = m->nccl.AllReduce(d->d_cnt, d->d_cnt + EMS_NCOUNTERS, EMS_NCOUNTERS, RCCL_INT64, RCCL_SUM, d->comm, d->cstream))) {
+        fprintf(stderr, "\nncclAllReduce on device %d: %s\n", d->hip_dev, m->nccl.GetErrorString(nrc));
+        return -1;
+    }
+    if (hipMemcpyAsync(v, d->d_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyDeviceToHost, d->cstream) != hipSuccess ||
+        hipStreamSynchronize(d->cstream) != hipSuccess) return -1;
+    return 0;
+}
+
+static void m_line(const ems_counters *run, void *c)                   /* NB_LDPC.c:498 */
+{
+    multi_ctx *m = (multi_ctx *)c;
+    const long long nb = run->c[EMS_CNT_FRAMES];
+    printf("\r<%d> FER= %d / %d = %f BER= %d / x = %f  avr_it=%.2f", (int)run->c[EMS_CNT_UNDETECTED], (int)run->c[EMS_CNT_ERR_FRAMES], (int)nb,
+           (double)run->c[EMS_CNT_ERR_FRAMES] / nb, (int)run->c[EMS_CNT_BIT_ERRORS],
+           (double)run->c[EMS_CNT_BIT_ERRORS] / ((double)nb * m->K * m->logGF), (double)run->c[EMS_CNT_SUM_IT] / nb);
+    fflush(stdout);
+}
+
+/* EMS_DEVICES: the whole simulation loop on the listed devices; fills the reference's counters.  Returns 0 or exits. */
+static int run_multi(const char *devlist, code_t *code, table_t *table, const ems_code_desc *desc, const ems_params *prm, int batch_env,
+                     long long n_frames, float EbN, int threads, int gpu_source, unsigned long long gpu_seed, long long first_frame,
+                     ems_counters *fin, int *batch_out)
+{
+    enum { MAXDEV = 64 };
+    int devs[MAXDEV], nd = 0;
+    for (const char *p = devlist; *p && nd < MAXDEV;) {
+        char *e;
+        const long v = strtol(p, &e, 10);
+        if (e == p) break;
+        devs[nd++] = (int)v;
+        p = (*e == ',') ? e + 1 : e;
+    }
+    if (nd < 1) { fprintf(stderr, "EMS_DEVICES=%s: no device\n", devlist); exit(EXIT_FAILURE); }
+    multi_ctx m;
+    memset(&m, 0, sizeof m);
+    if (rccl_load(&m.nccl)) exit(EXIT_FAILURE);
+    m.ndev = nd; m.code = code; m.table = table; m.EbN = EbN; m.gpu_source = gpu_source; m.gpu_seed = gpu_seed; m.first_frame = first_frame;
+    m.K = code->K; m.logGF = code->logGF;
+    m.threads_per_dev = threads / nd > 0 ? threads / nd : 1;
+    m.sigma_dev = (float)sqrt(1.0 / (2.0 * (double)code->rate * pow(10.0, (double)EbN / 10.0)));   /* channel.c:51 */
+    int batch = batch_env, rc;
+    if (batch <= 0 && (rc = ems_suggest_batch(desc, prm, devs[0], 2, &batch))) die("ems_suggest_batch", rc);
+    if ((long long)batch * nd > n_frames) batch = (int)((n_frames + nd - 1) / nd);      /* (no buffers for frames that are never drawn) */
+    if (batch < 1) batch = 1;
+    *batch_out = batch;
+    m.d = calloc((size_t)nd, sizeof *m.d);
+    void **comms = calloc((size_t)nd, sizeof *comms);
+    int nrc;
+    if ((nrc = m.nccl.CommInitAll(comms, nd, devs))) {                  /* one communicator per device, this process */
+        fprintf(stderr, "ncclCommInitAll(%d devices): %s\n", nd, m.nccl.GetErrorString(nrc));
+        exit(EXIT_FAILURE);
+    }
+    for (int i = 0; i < nd; i++) {
+        dev_ctx *d = &m.d[i];
+        d->hip_dev = devs[i];
+        d->comm = comms[i];
+        for (int s = 0; s < 2; s++) {
+            if ((rc = ems_create(&d->h[s], desc, prm, batch, devs[i]))) die("ems_create", rc);
+            if (gpu_source && (rc = ems_source_attach(d->h[s], code->matUT[0], code->Perm))) die("ems_source_attach", rc);
+            d->cw[s] = malloc(sizeof(int) * (size_t)batch * code->N);
+            d->noisy[s] = malloc(sizeof(float) * (size_t)batch * code->N * code->logGF);
+        }
+        d->iters = malloc(sizeof(int) * batch); d->synd = malloc(sizeof(int) * batch); d->nberr = malloc(sizeof(int) * batch);
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void **)&d->d_cnt, sizeof(long long) * 2 * EMS_NCOUNTERS) != hipSuccess) {
+            fprintf(stderr, "device %d: cannot set up the all-reduce buffers\n", devs[i]);
+            exit(EXIT_FAILURE);
+        }
+    }
+    fprintf(stderr, "[ems_sim] %d device(s) [%s], one RCCL all-reduce of %d int64 counters per round, batch %d frames per device and round, %d generator thread(s) per device\n",
+            nd, devlist, EMS_NCOUNTERS, batch, m.threads_per_dev);
+    const ems_multi_ops ops = {m_launch, m_collect, m_allreduce, m_line, &m};
+    if (ems_multi_run(&ops, nd, n_frames, batch, 40, fin)) { fprintf(stderr, "\nmulti-device run failed\n"); exit(EXIT_FAILURE); }
+    for (int i = 0; i < nd; i++) {
+        dev_ctx *d = &m.d[i];
+        (void)hipSetDevice(d->hip_dev);
+        (void)hipStreamSynchronize(d->cstream);
+        (void)m.nccl.CommDestroy(d->comm);
+        (void)hipFree(d->d_cnt);
+        (void)hipStreamDestroy(d->cstream);
+        for (int s = 0; s < 2; s++) { ems_destroy(d->h[s]); free(d->cw[s]); free(d->noisy[s]); }
+        free(d->iters); free(d->synd); free(d->nberr);
+    }
+    free(m.d); free(comms);
+    return 0;
 }
 
 int main(int argc, char *argv[])
@@ -129,6 +346,29 @@ int main(int argc, char *argv[])
         }
     ems_code_desc desc = {code.N, code.M, code.GF, code.logGF, code.nbBranch, code.rowDegree, col, coef};
     ems_params prm = {nbMax, NbOper, offset, NbIterMax, 1};
+    if (getenv("EMS_DEVICES")) {                                        /* one simulation on several GPUs of the node (run_multi) */
+        char note_m[40] = "FB30", file_m[128];
+        printf("\n\t Note             : %s\n", note_m);
+        sprintf(file_m, "./data/results_N%d_CR%0.2f_GF%d_IT%d_Offset%0.1f_nm%d_%s.txt", code.N, code.rate, code.GF, NbIterMax, offset, nbMax, note_m);
+        time_t now_m = time(NULL);
+        printf("Simulation started at time: %s \n", ctime(&now_m));
+        ems_counters fin;
+        memset(&fin, 0, sizeof fin);
+        struct timespec m0, m1;
+        clock_gettime(CLOCK_MONOTONIC, &m0);
+        int batch_m = 0;
+        run_multi(getenv("EMS_DEVICES"), &code, &table, &desc, &prm, batch, NbMonteCarlo, EbN, threads, gpu_source, gpu_seed, first_frame, &fin, &batch_m);
+        clock_gettime(CLOCK_MONOTONIC, &m1);
+        const double tm = (m1.tv_sec - m0.tv_sec) + 1e-9 * (m1.tv_nsec - m0.tv_nsec);
+        const int nbm = (int)fin.c[EMS_CNT_FRAMES], stopped = fin.c[EMS_CNT_ERR_FRAMES] == 40;
+        report(file_m, EbN, (int)fin.c[EMS_CNT_ERR_FRAMES], stopped ? nbm : nbm + 1, (int)fin.c[EMS_CNT_BIT_ERRORS], fin.c[EMS_CNT_SUM_IT], code.K, code.logGF);
+        fprintf(stderr, "[ems_sim] %d frames on EMS_DEVICES=%s, wall %.3f s incl. set-up (%.1f frames/s), batch %d per device\n", nbm, getenv("EMS_DEVICES"),
+                tm, tm > 0 ? nbm / tm : 0.0, batch_m);
+        free(col); free(coef);
+        FreeCode(&code);
+        FreeTable(&table);
+        return EXIT_SUCCESS;
+    }
     /* NH decoder handles (own streams) used round-robin: up to NH batches are in flight, the results of batch k
      * are fetched only after batch k+NH-1 has been launched, so the tail of a batch (its few frames that run every
      * iteration) overlaps the next ones.  EMS_INFLIGHT=1..4 (default 3; 2.0 dB, GF(256): 5.5 / 6.7 / 7.4 k frames/s). */
@@ -245,22 +485,7 @@ int main(int argc, char *argv[])
     clock_gettime(CLOCK_MONOTONIC, &t1);
     t_decode = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
-    const int nb_logged = stop ? nb : nb + 1;
-    printf(" \n results are printed in file %s \n", file_name);
-    now = time(NULL);
-    char *ts = ctime(&now);
-    FILE *op = fopen(file_name, "a");
-    if (!op) {
-        printf(" \n !! file not found \n ");
-    } else {
-        fprintf(op, " SNR:%.2f: \t FER= %d / %d = %f ", EbN, nbErroneousFrames, nb_logged, (double)nbErroneousFrames / nb_logged);
-        fprintf(op, " \t BER= %d / x = \t %f  avr_it= \t %.2f \t time: %s", total_errors,
-                (double)total_errors / ((double)nb_logged * K * logGF), (double)sum_it / nb_logged, ts);
-        fclose(op);
-    }
-    printf(" \n results printed \n ");
-    printf("\n");
-    printf("Simulation complete at time: %s", ts);
+    report(file_name, EbN, nbErroneousFrames, stop ? nb : nb + 1, total_errors, sum_it, K, logGF);
     fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; %s frame generation %.3f s on %d thread(s)\n",
             nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, gpu_source ? "device-side (no host)" : "host", t_gen, gpu_source ? 0 : threads);
 

@@ -1,0 +1,61 @@
+"""The C harness' multi-GPU Monte-Carlo loop (csrc/harness/ems_multi.h + ems_tally.h; SURVEY.md 8(e), north_star: "sharded across
+the 8 GPUs of one node with only an RCCL all-reduce of frame/bit-error counters").
+
+CPU part: tests/ctest/test_tally.c runs the very loop ems_sim runs -- one thread per device, two batches in flight per device, one
+all-reduce of the five counters per round, ordered tally -- with a fake N-device decode and a barrier-based all-reduce, under
+AddressSanitizer + UBSan, and compares the printed trace with the sequential single-device tally: same line after every frame,
+truncated at exactly the 40th erroneous frame, the same all-reduced totals on every device, batches launched ahead of the stop
+drained and dropped.  GPU part (-m gpu): `EMS_DEVICES=0 ems_sim ...` -- the same code with the real RCCL communicator
+(ncclCommInitAll + ncclAllReduce of 5 x ncclInt64) on the one GPU of the box -- reproduces the reference's traces."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLD, MAT, ROOT
+
+HARNESS = os.path.join(ROOT, "ems-decoder-of-nb-ldpc-codes_amd", "csrc", "harness")
+
+
+@pytest.fixture(scope="module")
+def tally_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("ctest") / "test_tally")
+    cmd = ["gcc", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + HARNESS, "-o", exe,
+           os.path.join(ROOT, "tests", "ctest", "test_tally.c")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    return exe
+
+
+@pytest.mark.parametrize("ndev,batch,frames,rate", [(1, 7, 500, 30), (2, 64, 5000, 30), (8, 16, 100000, 3), (3, 5, 200, 0), (8, 1536, 20000, 4),
+                                                     (5, 1, 300, 200), (4, 100, 250, 1000), (8, 256, 300, 50), (7, 33, 1000, 0), (2, 1, 1, 1000)])
+def test_fake_n_device_run_equals_sequential_tally(tally_exe, ndev, batch, frames, rate):
+    out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), str(rate)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = out.stdout.decode().splitlines()
+    assert len(lines) <= frames
+    if lines:
+        last = re.match(r"<(\d+)> FER= (\d+) / (\d+) ", lines[-1])
+        assert int(last.group(2)) <= 40 and (int(last.group(2)) == 40 or int(last.group(3)) == frames)
+
+
+def _trace(stdout):
+    return [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
+            re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", stdout.decode("latin-1"))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,batch", [("K2", 16), ("K3", 2), ("L4", 256)])
+def test_c_harness_multi_device_path_with_rccl_on_one_gpu(pkg, kat, tmp_path, case, batch):
+    """EMS_DEVICES=0: ncclCommInitAll over one device, the per-round ncclAllReduce, the ordered tally -- against the traces of the
+    real reference executable (K2 / K3: tests/golden/kat_traces.json; L4: 969 full-size frames to the 40th erroneous one)."""
+    k = kat[case] if case in kat else json.load(open(os.path.join(GOLD, "kat_long.json")))[case]
+    matrix = {"N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
+    out = subprocess.run([pkg.SIM_PATH] + [str(a) for a in (k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"])],
+                         cwd=str(tmp_path), env=dict(os.environ, EMS_DEVICES="0", EMS_BATCH=str(batch)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert b"RCCL all-reduce" in out.stderr
+    assert _trace(out.stdout) == [list(t) for t in k["trace"]]
