@@ -17,6 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("EMS_LIB") or os.path.join(PKG_DIR, "libems_hip.so")  # EMS_LIB: developer override (ablation builds)
 SIM_PATH = os.path.join(PKG_DIR, "ems_sim")
+SIM_V2_PATH = os.path.join(PKG_DIR, "ems_sim_v2")   # the older generation's harness (csrc/harness/ems_sim_v2.c)
 
 LLR_SUM, LLR_SSD, LLR_NEG = 0, 1, 2   # ems_abi.h: EMS_LLR_SUM / EMS_LLR_SSD / EMS_LLR_NEG
 EMS_OK, EMS_EINVAL, EMS_ENODEV, EMS_EHIP, EMS_EIO, EMS_ENOMEM, EMS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -287,6 +288,20 @@ class Decoder:
         B = self.v2_load_likelihood(like, like_idx)
         self.v2_decode(B)
         return self.results(B)
+
+    def v2_enable_snapshots(self, on=True):
+        """ems_v2_enable_snapshots: the BER samples of the older generation's main() (v2.c:2174-2243)."""
+        L = lib()
+        L.ems_v2_enable_snapshots.argtypes = [C.c_void_p, C.c_int]
+        _check(L.ems_v2_enable_snapshots(self.h, int(bool(on))))
+
+    def v2_snapshots(self, B):
+        """[B][5] bit errors of the decisions in force when iterations 9, 19, 29, 39, 49 begin (0 where the frame had stopped)."""
+        snap = np.zeros((B, 5), np.int32)
+        L = lib()
+        L.ems_v2_get_snapshots.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _check(L.ems_v2_get_snapshots(self.h, B, _ptr(snap)))
+        return snap
 
     def v2_state(self, frame):
         E, nm, N, q = self.code.desc.nbBranch, self.prm.nm, self.code.N, self.code.GF

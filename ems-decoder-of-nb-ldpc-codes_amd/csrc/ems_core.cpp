@@ -200,6 +200,8 @@ struct ems_handle {
     DevBuf<uint8_t> d_v2_vtoci;
     DevBuf<int16_t> d_v2_ctovi;
     bool v2_ready = false;
+    bool v2_snapshots = false;            // ems_v2_enable_snapshots
+    DevBuf<int> d_v2_snap;               // [max_batch][5]
     bool v2_from_rows = false;   // the likelihood rows came from ems_v2_channel_likelihood (no sorted staging copy)
     // device-side frame source (allocated by ems_source_attach)
     DevBuf<int> d_src_tptr, d_src_tcol, d_src_rptr, d_src_rcol, d_src_perm;
@@ -578,7 +580,7 @@ void ems_destroy(ems_handle *h)
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
-    h->d_v2_p_dst.release(); h->d_v2_p_last.release();
+    h->d_v2_p_dst.release(); h->d_v2_p_last.release(); h->d_v2_snap.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
@@ -1180,6 +1182,11 @@ int ems_v2_decode(ems_handle *h, int B)
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
     P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
+    P.v2_cw = nullptr; P.v2_snap = nullptr; P.K = h->K;
+    if (h->v2_snapshots) {                                              // main()'s BER samples (v2.c:2174-2243) against ems_set_codewords' codewords
+        if (!h->d_v2_snap.p && (r = h->d_v2_snap.alloc((size_t)h->max_batch * 5))) return r;
+        P.v2_cw = h->d_cw.p; P.v2_snap = h->d_v2_snap.p;
+    }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     const char *kn = "";
     HIP_TRY(ems_launch_decode_v2(P, B, h->stream, &kn));
@@ -1188,6 +1195,23 @@ int ems_v2_decode(ems_handle *h, int B)
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->have_dec_ev = true;
     return EMS_OK;
+}
+
+int ems_v2_enable_snapshots(ems_handle *h, int on)
+{
+    if (!h) return fail(EMS_EINVAL, "null handle");
+    h->v2_snapshots = on != 0;
+    return EMS_OK;
+}
+
+int ems_v2_get_snapshots(ems_handle *h, int B, int *snap)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!snap) return fail(EMS_EINVAL, "null argument");
+    if (!h->v2_snapshots || !h->d_v2_snap.p) return fail(EMS_EINVAL, "ems_v2_enable_snapshots + ems_v2_decode first");
+    HIP_TRY(hipMemcpyAsync(snap, h->d_v2_snap.p, sizeof(int) * 5 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    return sync_and_check(h);
 }
 
 int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *ctov, int *ctovi, float *app)

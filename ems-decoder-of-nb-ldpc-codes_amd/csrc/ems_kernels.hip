@@ -2338,6 +2338,23 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     if (active && rl == 0) (P.decide + (size_t)f * P.N)[n] = (uint8_t)lg;
 }
 
+// The older generation's main() samples the bit error count when iterations 9, 19, 29, 39 and 49 BEGIN (v2.c:2174-2243, before that
+// iteration's ComputeAPPLog / Decision): the decisions it reads are those of iterations 8, 18, ...  Called by the whole workgroup after
+// the Decision + Syndrom of iteration `sweep` when the frame goes on to iteration sweep + 1: bit errors over the first K symbols
+// (NB_LDPC.c:479-485 counting) into snap[sweep / 10].  acc: one LDS word, zero on entry and on exit.
+__device__ __forceinline__ void v2_snapshot(const EmsPlan &P, int f, int sweep, const uint8_t *t_i2b, unsigned *acc, int tid, int nthreads)
+{
+    if (!P.v2_snap || sweep % 10 != 8 || sweep > 48 || sweep + 1 >= P.nsweeps) return;   // (workgroup-uniform)
+    int n = 0;
+    for (int k = tid; k < P.K; k += nthreads)
+        n += __popc((unsigned)(t_i2b[P.decide[(size_t)f * P.N + k]] ^ t_i2b[P.v2_cw[(size_t)f * P.N + k]]));
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((tid & 63) == 0 && n) atomicAdd(acc, (unsigned)n);
+    __syncthreads();
+    if (tid == 0) { P.v2_snap[f * 5 + sweep / 10] = (int)*acc; *acc = 0u; }
+    __syncthreads();
+}
+
 template <int Q, int LPE = 16, int NM = 0, bool OCC4 = false>
 __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(const EmsPlan P)
 {
@@ -2366,7 +2383,8 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
     for (int i = tid; i < Q; i += blockDim.x) { t_i2b[i] = P.idx2bin[i]; t_b2i[i] = P.bin2idx[i]; }
     for (int i = tid; i < P.M; i += blockDim.x) done[i] = 0;
     cn_sched_build(sched, C.dc, C.nm, tid, blockDim.x);
-    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; first_bad[3] = 0u; }
+    if (P.v2_snap && tid < 5) P.v2_snap[f * 5 + tid] = 0;
     __syncthreads();
 
     int it = 0;
@@ -2432,6 +2450,7 @@ __global__ void __launch_bounds__(OCC4 ? 256 : 768, OCC4 ? 4 : 1) k_decode_v2(co
         if (tid == 0) *first_bad = 0xFFFFFFFFu;
         synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
         it = sweep + 1;
+        if (!(synd == 0 && P.early_exit)) v2_snapshot(P, f, sweep, t_i2b, first_bad + 3, tid, (int)blockDim.x);   // (the frame goes on)
         if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
             for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {          // (rows of 16 lanes here, whatever LPE is)
                 const int n = n0 + (lane >> 4);
@@ -2483,7 +2502,8 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
     for (int i = tid; i < Q; i += blockDim.x) { t_i2b[i] = P.idx2bin[i]; t_b2i[i] = P.bin2idx[i]; }
     for (int i = tid; i < ndw; i += blockDim.x) done[i] = 0u;
     cn_sched_build_dual(sched, DC, C.nm, tid, blockDim.x);
-    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; }
+    if (tid == 0) { *first_bad = 0xFFFFFFFFu; *next_task = 0; *spin_fail = 0; first_bad[3] = 0u; }
+    if (P.v2_snap && tid < 5) P.v2_snap[f * 5 + tid] = 0;
     __syncthreads();
 
     int it = 0;
@@ -2550,6 +2570,7 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
         if (tid == 0) *first_bad = 0xFFFFFFFFu;
         synd = (fb == 0xFFFFFFFFu) ? 0u : (fb & 0xFFu);
         it = sweep + 1;
+        if (!(synd == 0 && P.early_exit)) v2_snapshot(P, f, sweep, t_i2b, first_bad + 3, tid, (int)blockDim.x);   // (the frame goes on)
         if ((synd == 0 && P.early_exit) || sweep == P.nsweeps - 1) {      // leaving: store the APP rows of this iteration
             for (int n0 = wave * 4; n0 < P.N; n0 += nwaves * 4) {          // (rows of 16 lanes here)
                 const int n = n0 + (lane >> 4);

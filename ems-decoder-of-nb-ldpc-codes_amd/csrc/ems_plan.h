@@ -87,6 +87,11 @@ struct EmsPlan {
     const uint8_t *t_last;  // [M*dc]     per (task, edge): 1 when this check node is the LAST visitor of the edge's variable node in a sweep
     const int *p_dst;       // [n_pairs*2dc] t_dst by (pair, row) for the two-visit kernel
     const int *p_last;      // [n_pairs*2dc] t_last by (pair, row)
+    // the statistics of the older generation's main() (v2.c:2174-2243): bit errors of the decisions in force when iterations 9, 19, 29,
+    // 39, 49 begin, against the transmitted codewords -- null when not asked for
+    const int *v2_cw;       // [B][N] transmitted codewords (symbol indices)
+    int *v2_snap;           // [B][5]
+    int K;                  // N - M: symbols the bit errors are counted over
 };
 
 // Device-side frame source (ems_source.hip): the reference's encoder matrices in CSR.

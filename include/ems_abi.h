@@ -158,6 +158,13 @@ int ems_v2_decode(ems_handle *h, int B);
  * reference keeps as decoder.likelihood / likelihood_index ([N][GF] each, decreasing) for one frame. */
 int ems_v2_channel_likelihood(ems_handle *h, const float *obs_host, const float *att_host, const float *table_host, float sigma, int B);
 int ems_v2_get_sorted_likelihood(ems_handle *h, int frame, float *like, int *like_idx);
+/* The statistics the older generation's main() keeps (v2.c:2174-2291): with snapshots enabled, ems_v2_decode also counts, per frame,
+ * the bit errors (first K symbols, against the codewords of ems_set_codewords) of the hard decisions in force when iterations 9, 19,
+ * 29, 39 and 49 BEGIN -- v2.c samples before that iteration's ComputeAPPLog / Decision, so these are the decisions of iterations
+ * 8, 18, ... -- and 0 where the frame had stopped (or NbIterMax ended) before.  snap: [B][5].  The "> 12 bit errors" frame rule and
+ * the printed lines stay in the harness (csrc/harness/ems_sim_v2.c). */
+int ems_v2_enable_snapshots(ems_handle *h, int on);
+int ems_v2_get_snapshots(ems_handle *h, int B, int *snap /*[B][5]*/);
 /* initialisation again from the likelihoods already staged in HBM by the last ems_v2_load_likelihood (timed with
  * ems_last_llr_ms): lets a harness repeat a decode without the host upload */
 int ems_v2_reinit(ems_handle *h, int B);

@@ -207,3 +207,58 @@ def test_v2_long_golden_run_from_the_reference(pkg, orc, v2):
         st = dec.v2_state(b)
         assert [orc.crc32(st[k]) for k in STATE] == m[3:], (b, cases[b])
     dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the older generation's main(): BER samples at iterations 9/19/29/39/49, "> 12 bit errors", printed lines
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dual", [0, 2])
+def test_v2_snapshots_vs_oracle(pkg, v2, monkeypatch, dual):
+    """ems_v2_get_snapshots against the oracle: the sample taken when iteration 10 j + 9 begins is the bit error count of the
+    decisions after iterations 0 .. 10 j + 8, i.e. of an oracle decode with NbIterMax = 10 j + 8 -- or 0 when the frame had stopped
+    before (v2.c:2174-2243).  Small GF(256) code, all-zero codeword, frames from easy to hopeless; both kernel families."""
+    monkeypatch.setenv("EMS_DUAL", str(dual))
+    path = os.path.join(MAT, "KN_N128_K64_GF256.txt")
+    o = v2.V2Oracle(path)
+    cases = [(0.55, 31), (0.8, 32), (0.9, 33), (1.0, 34), (1.1, 35), (1.3, 36), (0.95, 37), (1.05, 38)]
+    pairs = [v2.synthetic_likelihood(o.N, 256, 8, o.o.idx2bin, sg, seed) for sg, seed in cases]
+    like, idx = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    B, itmax, nm, nop, off = len(cases), 52, 20, 40, 0.3
+    dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=B)
+    dec.v2_enable_snapshots(True)
+    dec.set_codewords(np.zeros((B, o.N), np.int32))
+    decide, iters, synd = dec.v2_decode_batch(like, idx)
+    snap = dec.v2_snapshots(B)
+    K = o.N - o.M
+    popc = np.array([bin(int(x)).count("1") for x in o.o.idx2bin])
+    seen = set()
+    for b in range(B):
+        for j in range(5):
+            it_j = 10 * j + 9                                     # the sample is taken iff iteration it_j is run: iters counts iterations run
+            want = 0
+            if iters[b] > it_j:
+                ref = o.decode(like[b], idx[b], nm, nop, off, it_j - 1)       # iterations 0 .. it_j - 1
+                want = int(popc[ref["decide"][:K]].sum())
+                seen.add(j)
+            assert snap[b, j] == want, (b, j, iters[b], snap[b].tolist(), want)
+    assert seen == {0, 1, 2, 3, 4} and (iters < 10).any()          # every sample exercised, and frames that stop before the first
+    dec.close()
+
+
+@pytest.mark.parametrize("case,batch", [("V1", 24), ("V2", 5), ("V3", 3)])
+def test_v2_harness_prints_the_lines_of_the_v2_executable(pkg, tmp_path, case, batch):
+    """csrc/harness/ems_sim_v2.c (host draws in the reference's drand48 order, GPU likelihoods + decode + BER samples) against every
+    statistics line the REAL EMS_HS_L-BubbleCheck_UBS_decoder_v2.c executable printed (tests/golden/v2_traces.json, generated by
+    tests/golden/make_golden_v2_trace.py from oracle/_ref/essai_v2): five lines per frame, frame after frame."""
+    import json
+    import re
+    import subprocess
+    path = os.path.join(ROOT, "tests", "golden", "v2_traces.json")
+    if not os.path.exists(path) or case not in json.load(open(path)):
+        pytest.skip("tests/golden/v2_traces.json has no case " + case)
+    k = json.load(open(path))[case]
+    out = subprocess.run([pkg.SIM_V2_PATH] + [str(a) for a in (k["frames"], k["NbIterMax"], os.path.join(MAT, k["matrix"]), k["EbN"], k["nm"], k["offset"], k["NbOper"])],
+                         cwd=str(tmp_path), env=dict(os.environ, EMS_BATCH=str(batch)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = re.findall(r"<\d+> FER= \d+/ \d+ = \S+ BER= \d+/ \d+ = \S+", out.stdout.decode("latin-1"))
+    assert lines == k["lines"]
