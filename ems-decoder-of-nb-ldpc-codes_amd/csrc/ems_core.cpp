@@ -181,6 +181,9 @@ struct ems_handle {
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
+    bool regular = true;                 // every check node has degree dc; else dc = the largest degree and the tables below are used
+    std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
+    DevBuf<int> d_row_ptr, d_t_dc, d_t_e0;
     std::vector<int> p_cn, p_vn, p_lh, p_pred, p_task;   // check nodes in pairs (k_decode_dual), see build_pairs; p_task: task index per (pair, member), -1 = none
     std::vector<int> v2_p_dst, v2_p_last;
     int n_pairs = 0;   // iso_vn: variable nodes no check node touches
@@ -366,6 +369,9 @@ int refresh_plan(ems_handle *h)
     P.occ4 = 0;
     P.stamps = h->d_stamps.p;
     P.fail = h->d_fail.p;
+    P.cn_ptr = h->d_row_ptr.p;
+    P.t_dc = h->regular ? nullptr : h->d_t_dc.p;                // non-null = irregular code: generic one-visit kernel, per-visit degree
+    P.t_e0 = h->regular ? nullptr : h->d_t_e0.p;
     return EMS_OK;
 }
 
@@ -396,20 +402,27 @@ void build_tasks(ems_handle *h, const ems_code_desc *c)
         std::vector<int> task_of(h->M), last_cn(h->N, -1);
         for (int i = 0; i < h->M; ++i) task_of[h->lvl_cn[i]] = i;
         std::vector<int> pred_cn((size_t)E, -1);
+        std::vector<long> rp(h->M + 1, 0);                         // first edge of each check node
+        for (int m = 0; m < h->M; ++m) rp[m + 1] = rp[m] + c->rowDegree[m];
         for (int m = 0; m < h->M; ++m)
-            for (int i = 0; i < h->dc; ++i) {
-                const int v = c->col[m * h->dc + i];
-                pred_cn[(size_t)m * h->dc + i] = last_cn[v];
+            for (int i = 0; i < c->rowDegree[m]; ++i) {
+                const int v = c->col[rp[m] + i];
+                pred_cn[(size_t)rp[m] + i] = last_cn[v];
                 last_cn[v] = m;
             }
-        h->t_vn.resize(E); h->t_lh.resize(E); h->t_pred.resize(E);
+        // per (task, edge row) tables with the stride of the largest degree; the rows a shorter check node leaves over repeat its
+        // last edge (they shadow it, their stores are masked) and wait for nothing
+        const size_t T = (size_t)h->M * h->dc;
+        h->t_vn.resize(T); h->t_lh.resize(T); h->t_pred.resize(T);
+        h->t_dc.resize(h->M); h->t_e0.resize(h->M);
         for (int i = 0; i < h->M; ++i) {
-            const int m = h->lvl_cn[i];
+            const int m = h->lvl_cn[i], dm = c->rowDegree[m];
+            h->t_dc[i] = dm; h->t_e0[i] = (int)rp[m];
             for (int k = 0; k < h->dc; ++k) {
-                const size_t e = (size_t)m * h->dc + k;
+                const size_t e = (size_t)rp[m] + std::min(k, dm - 1);
                 h->t_vn[(size_t)i * h->dc + k] = c->col[e];
                 h->t_lh[(size_t)i * h->dc + k] = c->coef[e] - 1;
-                h->t_pred[(size_t)i * h->dc + k] = pred_cn[e] < 0 ? -1 : task_of[pred_cn[e]];
+                h->t_pred[(size_t)i * h->dc + k] = (k >= dm || pred_cn[e] < 0) ? -1 : task_of[pred_cn[e]];
             }
         }
         // Static SIMD-arbitration priority of each visit from its slack in the sweep's dependency DAG:
@@ -585,7 +598,7 @@ void ems_destroy(ems_handle *h)
     h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
-    h->d_fail.release();
+    h->d_fail.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -619,14 +632,25 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
 
     // The kernels split a wave into dc equal edge rows, so the check degree must be constant (the
     // reference sizes its per-CN scratch by rowDegree[0] and only warns otherwise, NB_LDPC.c:166-183).
-    h->dc = c->rowDegree[0];
+    // Check degrees.  A regular code (every BASELINE matrix) runs the kernels built for its degree.  An irregular one -- the reference
+    // only warns about it and sizes its per-check-node scratch by rowDegree[0] (NB_LDPC.c:166-183, init.c:320): it is well defined
+    // there as long as row 0 has the largest degree -- runs the generic one-visit kernel laid out for the LARGEST degree, every
+    // visit with its own degree: the edge rows a shorter check node leaves over idle along, its elementary-step schedule is the one
+    // of its degree (bubble_decoder.c:166-227 with dc = rowDegree[node]).
+    h->dc = 0;
     long E = 0;
+    h->row_ptr.assign(c->M + 1, 0);
     for (int m = 0; m < c->M; ++m) {
-        if (c->rowDegree[m] != h->dc) return bail(fail(EMS_EUNSUPPORTED, "irregular check degree (row %d has %d, row 0 has %d)", m, c->rowDegree[m], h->dc));
+        if (c->rowDegree[m] < 2) return bail(fail(EMS_EUNSUPPORTED, "check node %d has degree %d: at least 2", m, c->rowDegree[m]));
+        h->dc = std::max(h->dc, c->rowDegree[m]);
+        h->regular = h->regular && c->rowDegree[m] == c->rowDegree[0];
         E += c->rowDegree[m];
+        h->row_ptr[m + 1] = (int)E;
     }
     if (E != c->nbBranch) return bail(fail(EMS_EINVAL, "nbBranch does not match the row degrees"));
-    if (!ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "check degree %d > 16 is not built", h->dc));
+    if (!ems_lpe_for(h->dc))
+        return bail(fail(EMS_EUNSUPPORTED, "check degree %d: the kernels give every edge of a check node a row of at least 4 of the wavefront's 64 lanes, "
+                                           "i.e. at most 16 edges (the reference's matrices stop at 12)", h->dc));
     if (h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 
@@ -644,7 +668,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
             if (!touched[n]) h->iso_vn.push_back(n);
     }
     build_tasks(h, c);
-    if (h->dc == 4 || h->dc == 8) build_pairs(h);
+    if (h->regular && (h->dc == 4 || h->dc == 8)) build_pairs(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(EMS_EHIP, "hipEventCreate failed"));
@@ -655,7 +679,8 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
-        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)))
+        (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)) ||
+        (r = h->d_row_ptr.upload(h->row_ptr)) || (r = h->d_t_dc.upload(h->t_dc)) || (r = h->d_t_e0.upload(h->t_e0)))
         return bail(r);
     if (hipMemset(h->d_fail.p, 0, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&h->fail_host, sizeof(int), hipHostMallocDefault) != hipSuccess)
         return bail(fail(EMS_EHIP, "allocation of the failure word failed"));
@@ -770,6 +795,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     P.occ4 = 0;
     P.dual = 0;
     P.twin = 0;
+    if (!h->regular) return;                                    // irregular check degrees: the generic one-visit kernel in the plan's shape
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
     };
@@ -1014,6 +1040,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
 static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
+    if (!h->regular) return fail(EMS_EUNSUPPORTED, "v2 flavour: irregular check degrees are not built");
     if (!ems_lpe_for(h->dc)) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 16 is not built", h->dc);
     if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
     // the reference's Flag trick (v2.c:2157) needs exactly two edges per variable node

@@ -782,6 +782,7 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
 struct Cfg {
     int dc, nm, nbOper, T1, q, nsteps, n_lists;
     float offset;
+    bool onfly = false;   // the elementary-step tasks of a visit are computed from its degree (irregular codes) instead of read from the table
 };
 
 // list ids inside one check-node visit: inputs 0..dc-1, prefixes P(k), suffixes S(k), merges M(k)
@@ -864,10 +865,11 @@ template <int TL = 16>
 __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens, unsigned *tbl, uint8_t *picks, const uint2 *sched,
                                         int lane, bool literal, unsigned *bins ST_PARAMS)
 {
-    const bool fast = !literal && C.nbOper <= ES_MAX_STEPS;
+    const bool fast = !literal && C.nbOper <= ES_MAX_STEPS && C.nm <= EMS_FAST_NM;   // (a pick byte holds a list position in 5 bits)
     const bool q16 = fast && bins != nullptr && C.q == 16 && C.nm == 8;
     auto task_of = [&](int t) {
         const bool wide = TL == 8 && dual_stage_wide(C.dc, t);      // (two-visit waves: see dual_stage_wide)
+        if (TL == 16 && C.onfly) return cn_task(C.dc, list_stride(C.nm), t, lane / 16);   // this visit's own degree
         return sched[(t - 1) * 8 + (wide ? lane / 16 : lane / TL)];
     };
 #ifdef EMS_TASK_PREFETCH
@@ -1141,6 +1143,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
     // the set bits -- a lane owns EPL symbols but only one or two survive
     constexpr bool BYMASK = (G::EPL >= 4) && (G::EPL <= 32) && (Q > SEL_CAP);   // (the mask is one 32-bit word)
     unsigned am = 0u;
+    if (nm > SEL_CAP) return false;                    // more entries wanted than survivor slots: the literal nm rounds (wave-uniform)
     // ---- A ----
     const float lmin = array_min_f(mvc);
     const float rmin = row_minmax_f<LPE, false>(lmin);
@@ -1322,7 +1325,7 @@ __device__ __forceinline__ bool select_threshold(const float (&mvc)[Geo<Q, LPE>:
 // the global stores of a half that has no visit of its own (it shadows the other half's inputs).
 // ------------------------------------------------------------------------------------------------
 template <int Q, int LPE, bool DUAL = false>
-__device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int cn, int vn, int lh, bool first_sweep,
+__device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f, int e0, int vn, int lh, bool first_sweep,
                                            const uint8_t *t_i2b, const uint8_t *t_b2i, float *dense, EmsEntry *surv,
                                            EmsEntry *lists, int *lens, uint8_t *picks, const uint2 *sched, int oid, int lane,
                                            bool gact ST_PARAMS)
@@ -1354,7 +1357,7 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
         rowact = DUAL ? true : row < C.dc;  // the row computes (LDS side)
         stact = DUAL ? gact : rowact;       // ... and stores its results to HBM
         t = DUAL ? (row % DCD) : (rowact ? row : C.dc - 1);   // idle rows shadow the last edge, stores masked
-        edge = cn * C.dc + t;
+        edge = e0 + t;                      // e0: first edge of the check node this lane works for
         // frame bases are wave-uniform (scalar registers); the per-lane part is a 32-bit offset
         app_row = P.app + (size_t)f * P.N * Q + (unsigned)vn * (unsigned)Q;
         rec = P.ctov + (size_t)f * P.E * P.rec_bytes + (unsigned)edge * (unsigned)P.rec_bytes;
@@ -1379,6 +1382,8 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
         int rg[NREC];
 #pragma unroll
         for (int c = 0; c < NREC; ++c) {
+            rv[c] = 0.0f; rg[c] = 0;
+            if (c * LPE >= nm) continue;                 // (no entry of the record lives there)
             const int k = rl + c * LPE;
             const int kk = k < nm ? k : 0;
             rv[c] = reinterpret_cast<const float *>(rec)[kk];
@@ -1594,23 +1599,28 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) 
             if (lane == 0) i = atomicAdd(next_task, 1u);
             return (int)__builtin_amdgcn_readfirstlane((int)i);
         };
+        // Irregular check degrees (generic instantiations only): C.dc is the LARGEST degree -- it fixes the lane rows and the stride of the
+        // task tables -- and every visit brings its own degree and first edge (t_dc / t_e0); a regular code has them implied.
+        const bool irregular = DC == 0 && P.t_dc != nullptr;
         int cur = claim();
-        int cn = 0, vn = 0, lh = 0, pred = -1;
+        int cn = 0, vn = 0, lh = 0, pred = -1, dcv = C.dc, e0v = 0;
         if (cur < P.M) {
             cn = P.t_cn[cur];                                  // check node | priority << 24
             vn = P.t_vn[cur * C.dc + trow];
             lh = P.t_lh[cur * C.dc + trow];
             pred = P.t_pred[cur * C.dc + trow];
+            if (irregular) { dcv = P.t_dc[cur]; e0v = P.t_e0[cur]; }
         }
         while (cur < P.M) {                                    // NB_LDPC.c:320, in dependency order
             // claim the following task now and fetch its descriptor under the current visit
             const int nxt = claim();
-            int ncn = 0, nvn = 0, nlh = 0, npred = -1;
+            int ncn = 0, nvn = 0, nlh = 0, npred = -1, ndcv = C.dc, ne0v = 0;
             if (nxt < P.M) {
                 ncn = P.t_cn[nxt];
                 nvn = P.t_vn[nxt * C.dc + trow];
                 nlh = P.t_lh[nxt * C.dc + trow];
                 npred = P.t_pred[nxt * C.dc + trow];
+                if (irregular) { ndcv = P.t_dc[nxt]; ne0v = P.t_e0[nxt]; }
             }
             // wait for the previous visitors of my variable nodes (same sweep)
             {
@@ -1641,11 +1651,21 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) 
 #endif
             }
             STAMP(4);
-            process_cn<Q, LPE>(P, C, f, cn & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true ST_ARGS);
+            if (irregular) {
+                // this visit's degree: its rows, its forward / backward / merge schedule (bubble_decoder.c:166-227 with dc = rowDegree[node]),
+                // the list that holds each edge's output (:231-254); rows beyond it shadow its last edge with their stores masked
+                Cfg Cv = C;
+                Cv.dc = dcv; Cv.nsteps = dcv - 2; Cv.n_lists = dcv + 3 * (dcv - 2); Cv.onfly = true;
+                const int tv = row < dcv ? row : dcv - 1;
+                const int oidv = tv == 0 ? list_S(dcv, 1) : (tv == dcv - 1 ? list_P(dcv, dcv - 2) : list_M(dcv, tv - 1));
+                process_cn<Q, LPE>(P, Cv, f, e0v, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oidv, lane, true ST_ARGS);
+            } else {
+                process_cn<Q, LPE>(P, C, f, (cn & 0xFFFFFF) * C.dc, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true ST_ARGS);
+            }
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cur = nxt; cn = ncn; vn = nvn; lh = nlh; pred = npred;
+            cur = nxt; cn = ncn; vn = nvn; lh = nlh; pred = npred; dcv = ndcv; e0v = ne0v;
         }
         STAMP(6);
         __syncthreads();
@@ -1655,8 +1675,8 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) 
         //      sum; 0 iff codeword.  One thread per check node.
         for (int c = tid; c < P.M; c += blockDim.x) {
             unsigned acc = 0;
-            for (int i = 0; i < C.dc; ++i) {
-                const int ed = c * C.dc + i;
+            const int e_lo = DC > 0 ? c * DC : P.cn_ptr[c], e_hi = DC > 0 ? e_lo + DC : P.cn_ptr[c + 1];
+            for (int ed = e_lo; ed < e_hi; ++ed) {
                 const int x = P.decide[(size_t)f * P.N + P.cn_vn[ed]];
                 acc ^= t_i2b[gf_mul_log(x, P.cn_lh[ed], Q - 1)];
             }
@@ -1825,7 +1845,7 @@ __global__ void __launch_bounds__(DC == 4 ? 256 : EMS_DC8_WAVES * 64, DC == 4 ? 
                 }
             }
             STAMP(4);
-            process_cn<Q, LPE, true>(P, C, f, cnw & 0xFFFFFF, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
+            process_cn<Q, LPE, true>(P, C, f, (cnw & 0xFFFFFF) * DC, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicOr(&done[cur >> 5], 1u << (cur & 31));
@@ -1936,7 +1956,7 @@ __global__ void __launch_bounds__(64, Q == 64 ? 16 : 12) k_decode_twin(const Ems
         for (int c = 0; c < P.M; ++c) {                        // NB_LDPC.c:320, reference order
             const int vn = P.cn_vn[c * DC + t];
             const int lh = P.cn_lh[c * DC + t];
-            process_cn<Q, LPE, true>(P, C, fl, c, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
+            process_cn<Q, LPE, true>(P, C, fl, c * DC, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, gact ST_ARGS);
         }
         // ---- Syndrom (tools.c:284-299) of both frames: lanes 0..31 take the check nodes of the first, 32..63 of the second ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2172,7 +2192,7 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
 
     // ---- forward / backward / merge elementary steps (:1798-1850), one lane per task ----
     unsigned *seen = reinterpret_cast<unsigned *>(dense);
-    const bool fast = C.nbOper <= ES_MAX_STEPS;              // pick areas hold 64 steps; longer runs take the literal form
+    const bool fast = C.nbOper <= ES_MAX_STEPS && nm <= EMS_FAST_NM;   // pick areas hold 64 steps and 5-bit positions; else the literal form
 #if defined(EMS_ABLV) && EMS_ABLV == 1     // ablation builds of the v2 flavour (timing experiments, results wrong): no elementary steps
     if (false) {
 #else
@@ -2883,7 +2903,7 @@ __global__ void k_es_unit(const float *in1, const float *in2, const int *idx1, c
     wave_lds_sync();
     const bool g0 = lane < 16;
     // the fast form needs every valid value in [0, 1e4) (true inside the decoder); anything else -> literal loop
-    if (nbOper <= ES_MAX_STEPS && __ballot(big) == 0ull)
+    if (nbOper <= ES_MAX_STEPS && nm <= EMS_FAST_NM && __ballot(big) == 0ull)
     {
         ST_DUMMY
         es_stage_fast(lists, lens, tbl, picks, q, lane, es_task(g0 ? 0 : -1, g0 ? 1 : -1, g0 ? 2 : -1, nmp), nm, nbOper, min(nbOper, nm + 3) ST_ARGS);
@@ -3087,7 +3107,8 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
 {
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
-    const bool spec = spec_ok(P);
+    const bool spec = spec_ok(P) && P.t_dc == nullptr;       // (irregular check degrees: the generic kernels with per-visit degrees)
+    if (P.t_dc != nullptr && (P.twin || P.dual || P.occ4)) return hipErrorInvalidValue;
     if (P.twin) {
         if (!ems_has_twin_kernel(P)) return hipErrorInvalidValue;
         return launch_decode_twin_t<64, 16, 4>(P, B, st);

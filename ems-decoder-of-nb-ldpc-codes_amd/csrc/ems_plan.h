@@ -15,7 +15,8 @@ struct EmsEntry {
 #define EMS_SENTINEL 1e5f
 #define EMS_S_INVALID 0x100u
 #define EMS_S_BOUND 0x200u
-#define EMS_MAX_NM 32      // messages longer than this are not built (reference usage: 8..30)
+#define EMS_MAX_NM 40      // messages longer than this are not built (reference usage: 8..30); above EMS_FAST_NM the literal forms run
+#define EMS_FAST_NM 32     // the merge form of the elementary step records a list position in 5 bits, the selection keeps 32 survivors
 #define EMS_MAX_STEPS 14   // dc-2 forward/backward steps (dc <= 16)
 
 // Compact check-to-variable record kept in HBM per (frame, edge).  The reference stores a dense
@@ -48,6 +49,10 @@ struct EmsPlan {
     const int *t_vn;        // [M*dc] its variable nodes
     const int *t_lh;        // [M*dc] log of its coefficients
     const int *t_pred;      // [M*dc] task index of the previous visitor of that variable node in this sweep, or -1
+    // irregular check degrees (dc = the largest; tables above keep its stride): per task its own degree and its first edge; null = regular
+    const int *t_dc;        // [M]
+    const int *t_e0;        // [M]
+    const int *cn_ptr;      // [M+1] first edge of every check node (cn_vn / cn_lh are flat [E])
     // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)

@@ -226,7 +226,7 @@ def test_compute_entry_points_fail_loudly_without_gpu(pkg):
 
 def test_parameter_validation(pkg):
     c = pkg.Code(os.path.join(MAT, "N96_K48_GF64"))
-    for nm in (4, 33, 65):
+    for nm in (4, 41, 65):
         with pytest.raises(pkg.EmsError) as e:
             pkg.Decoder(c, nm, 32, 0.3, 10, max_batch=2)
         assert e.value.code in (pkg.EMS_EINVAL, pkg.EMS_ENODEV)

@@ -165,6 +165,31 @@ def test_decode_n96_other_parameters(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Mat24_N192_M96", 24, 48, 1.0, 20, 1.75, 24)        # NB_LDPC.c:55-57
 
 
+def test_decode_irregular_check_degrees_vs_oracle(pkg, orc):
+    """SURVEY.md 8(f) f4, second half: check degrees 3 / 4 / 5 in one code (tests/golden/make_irregular_matrix.py; row 0 carries the
+    largest, where the reference itself is well defined -- kat_traces.json I1 / I2 are the real executable's traces and the oracle
+    reproduces them, tests/test_oracle_golden.py).  The generic one-visit kernel laid out for the largest degree, every visit with its
+    own degree: whole-frame state (hard decisions, iterations, syndrome, bit errors, APP, every C->V row) against the oracle."""
+    _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF64", 12, 24, 0.3, 12, 3.0, 24)
+    _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF64", 16, 19, 1.0, 6, 1.0, 8, early_exit=False)
+    _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF256", 16, 32, 0.5, 10, 3.5, 16)
+    _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF256", 20, 40, 0.3, 8, 2.0, 300)          # more frames than one wave of workgroups
+    code = pkg.Code(os.path.join(MAT, "Irr345_N60_M24_GF256"))
+    dec = pkg.Decoder(code, 20, 40, 0.3, 8, max_batch=2)
+    with pytest.raises(pkg.EmsError):                       # the older generation's flavour is built for regular codes
+        dec.v2_load_likelihood(np.zeros((1, code.N, 256), np.float32), np.zeros((1, code.N, 256), np.int32))
+    dec.close()
+
+
+def test_decode_messages_longer_than_32_entries_vs_oracle(pkg, orc):
+    """nm up to 40 (the reference caps nm nowhere; kat_traces.json N40 / N36 are its own traces at nm = 40 and 36): beyond the 32
+    entries the merge form and the threshold selection hold, the literal forms run -- same bits."""
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 40, 60, 0.3, 10, 2.0, 24)
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 33, 66, 0.5, 6, 1.0, 8, early_exit=False)
+    _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 40, 80, 0.3, 8, 2.5, 12)
+    _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF256", 36, 72, 0.3, 8, 3.0, 8)
+
+
 def test_decode_generic_kernels_other_degrees(pkg, orc):
     """Codes outside the specialised (dc, nm) instantiations: dc = 6, 8 and 12 over GF(64) (rows of 8 and 4
     lanes), GF(256) with dc = 4 at a non-default nm, GF(256) with dc = 8."""
@@ -254,7 +279,7 @@ def test_set_params_switches_kernels_and_keeps_the_record_layout(pkg, orc, monke
 def test_unsupported_configurations_fail_loudly(pkg):
     code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
     with pytest.raises(pkg.EmsError) as e:
-        pkg.Decoder(code, 40, 60, 0.3, 10, max_batch=1)          # nm > 32
+        pkg.Decoder(code, 41, 60, 0.3, 10, max_batch=1)          # nm > 40 (EMS_MAX_NM)
     assert e.value.code == pkg.EMS_EINVAL
 
 
@@ -595,7 +620,7 @@ def _run_ems_sim(pkg, args, batch, cwd):
     return tr
 
 
-@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128)])
+@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8)])
 def test_c_harness_reproduces_reference_traces(pkg, kat, tmp_path, name, batch):
     """The C Monte-Carlo harness (same argv as the reference) on the GPU prints the reference's trace."""
     k = kat[name]

@@ -124,7 +124,7 @@ def test_trajectory_big_codes(orc, tag, mat, nm, nop):
     assert (res["sweep_crc"] == g[tag + "_crc"]).all() and (res["sweep_decide"] == g[tag + "_dec"]).all()
 
 
-@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5"])
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5", "I1", "I2", "N40", "N36"])
 def test_kat_traces(orc, kat, name):
     """End-to-end FER/BER/avr_it traces printed by the reference executable."""
     k = kat[name]
@@ -132,6 +132,6 @@ def test_kat_traces(orc, kat, name):
     if name in ("K1", "K2"):
         matrix = "KN_N96_K48_GF64.txt"
     o = orc.Oracle(os.path.join(MAT, matrix))
-    rec = o.sim(orc.Rng(0), k["EbN"], k["nm"], k["NbOper"], k["offset"], k["NbIterMax"], k["frames"])
+    rec = o.sim(orc.Rng(0), k["EbN"], k["nm"], k["NbOper"], k["offset"], k["NbIterMax"], len(k["trace"]))   # (I1 / I2 end at the 40th erroneous frame)
     tr = orc.trace_from_records(rec, o.K, o.logq)
     assert [list(t) for t in tr] == [list(t) for t in k["trace"]]
