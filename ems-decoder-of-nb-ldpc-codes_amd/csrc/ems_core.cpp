@@ -199,9 +199,8 @@ struct ems_handle {
     std::vector<uint8_t> v2_t_last;
     DevBuf<uint8_t> d_v2_t_last;
     DevBuf<int> d_v2_t_dst, d_v2_vn_edge, d_v2_stage_idx, d_v2_bad, d_v2_p_dst, d_v2_p_last;
-    DevBuf<float> d_v2_like, d_v2_vtoc, d_v2_ctov, d_v2_hint, d_v2_app, d_v2_stage_like;
-    DevBuf<uint8_t> d_v2_vtoci;
-    DevBuf<int16_t> d_v2_ctovi;
+    DevBuf<float> d_v2_like, d_v2_app, d_v2_stage_like;
+    DevBuf<uint8_t> d_v2_msg;            // [max_batch][E][2][ems_v2_rec_bytes(nm)] the V->C and C->V records of every edge
     bool v2_ready = false;
     bool v2_snapshots = false;            // ems_v2_enable_snapshots
     DevBuf<int> d_v2_snap;               // [max_batch][5]
@@ -595,8 +594,8 @@ void ems_destroy(ems_handle *h)
     h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
     h->d_v2_p_dst.release(); h->d_v2_p_last.release(); h->d_v2_snap.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
-    h->d_v2_vtoc.release(); h->d_v2_ctov.release(); h->d_v2_hint.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
-    h->d_v2_vtoci.release(); h->d_v2_ctovi.release(); h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
+    h->d_v2_msg.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
+    h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
     h->d_fail.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
@@ -1081,8 +1080,7 @@ static int v2_prepare(ems_handle *h)
     int r;
     if ((r = h->d_v2_p_dst.upload(h->v2_p_dst)) || (r = h->d_v2_p_last.upload(h->v2_p_last))) return r;
     if ((r = h->d_v2_t_dst.upload(h->v2_t_dst)) || (r = h->d_v2_t_last.upload(h->v2_t_last)) || (r = h->d_v2_vn_edge.upload(h->v2_vn_edge)) || (r = h->d_v2_like.alloc(B * h->N * h->q)) ||
-        (r = h->d_v2_app.alloc(B * h->N * h->q)) || (r = h->d_v2_vtoc.alloc(B * h->E * nm)) || (r = h->d_v2_ctov.alloc(B * h->E * nm)) ||
-        (r = h->d_v2_vtoci.alloc(B * h->E * nm)) || (r = h->d_v2_ctovi.alloc(B * h->E * nm)) || (r = h->d_v2_hint.alloc(B * h->E)) ||
+        (r = h->d_v2_app.alloc(B * h->N * h->q)) || (r = h->d_v2_msg.alloc(B * h->E * 2 * (size_t)ems_v2_rec_bytes((int)nm))) ||
         (r = h->d_v2_stage_like.alloc(B * h->N * h->q)) || (r = h->d_v2_stage_idx.alloc(B * h->N * h->q)) || (r = h->d_v2_bad.alloc(1)))
         return r;
     h->v2_ready = true;
@@ -1101,7 +1099,7 @@ int ems_v2_load_likelihood(ems_handle *h, const float *like, const int *like_idx
     HIP_TRY(hipMemcpyAsync(h->d_v2_stage_idx.p, like_idx, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_v2_bad.p, 0, sizeof(int), h->stream));
     HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
-                               h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+                               h->d_v2_msg.p, ems_v2_rec_bytes(h->nm_alloc), h->d_v2_bad.p, h->stream));
     int bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, h->d_v2_bad.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1133,7 +1131,7 @@ int ems_v2_channel_likelihood(ems_handle *h, const float *obs_host, const float 
     HIP_TRY(hipMemsetAsync(h->d_v2_bad.p, 0, sizeof(int), h->stream));
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(ems_launch_llr_const(h->d_noisy.p, h->d_att.p, h->d_ctable.p, h->q, 2, EMS_LLR_NEG, sigma, (size_t)B * h->N, h->d_b2i.p, h->d_v2_like.p, h->stream));
-    HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p,
+    HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_msg.p, ems_v2_rec_bytes(h->nm_alloc),
                                     h->d_v2_bad.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
@@ -1172,11 +1170,11 @@ int ems_v2_reinit(ems_handle *h, int B)
     if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (h->v2_from_rows)                                       // (the likelihood rows themselves are never modified by a decode)
-        HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_vtoc.p, h->d_v2_vtoci.p,
-                                        h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+        HIP_TRY(ems_launch_v2_init_rows(h->d_v2_like.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_msg.p, ems_v2_rec_bytes(h->nm_alloc),
+                                        h->d_v2_bad.p, h->stream));
     else
         HIP_TRY(ems_launch_v2_init(h->d_v2_stage_like.p, h->d_v2_stage_idx.p, B, h->N, h->q, h->prm.nm, h->E, h->d_v2_vn_edge.p, h->d_v2_like.p,
-                                   h->d_v2_vtoc.p, h->d_v2_vtoci.p, h->d_v2_hint.p, h->d_v2_bad.p, h->stream));
+                                   h->d_v2_msg.p, ems_v2_rec_bytes(h->nm_alloc), h->d_v2_bad.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
     return EMS_OK;
@@ -1207,8 +1205,7 @@ int ems_v2_decode(ems_handle *h, int B)
         }
     }
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
-    P.v2_like = h->d_v2_like.p; P.v2_vtoc = h->d_v2_vtoc.p; P.v2_vtoci = h->d_v2_vtoci.p; P.v2_ctov = h->d_v2_ctov.p;
-    P.v2_ctovi = h->d_v2_ctovi.p; P.v2_hint = h->d_v2_hint.p; P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
+    P.v2_like = h->d_v2_like.p; P.v2_msg = h->d_v2_msg.p; P.v2_rec = ems_v2_rec_bytes(h->nm_alloc); P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
     P.v2_cw = nullptr; P.v2_snap = nullptr; P.K = h->K;
     if (h->v2_snapshots) {                                              // main()'s BER samples (v2.c:2174-2243) against ems_set_codewords' codewords
         if (!h->d_v2_snap.p && (r = h->d_v2_snap.alloc((size_t)h->max_batch * 5))) return r;
@@ -1248,18 +1245,19 @@ int ems_v2_get_state(ems_handle *h, int frame, float *vtoc, int *vtoci, float *c
     if (frame < 0 || !h->v2_ready) return fail(EMS_EINVAL, "bad argument");
     if (h->prm.nm != h->nm_alloc) return fail(EMS_EINVAL, "v2 flavour: nm must equal the value given at create");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    const size_t ne = (size_t)h->E * h->nm_alloc, off = (size_t)frame * ne;
-    if (vtoc) HIP_TRY(hipMemcpy(vtoc, h->d_v2_vtoc.p + off, ne * sizeof(float), hipMemcpyDeviceToHost));
-    if (ctov) HIP_TRY(hipMemcpy(ctov, h->d_v2_ctov.p + off, ne * sizeof(float), hipMemcpyDeviceToHost));
-    if (vtoci) {
-        std::vector<uint8_t> t(ne);
-        HIP_TRY(hipMemcpy(t.data(), h->d_v2_vtoci.p + off, ne, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ne; ++i) vtoci[i] = t[i];
-    }
-    if (ctovi) {
-        std::vector<int16_t> t(ne);
-        HIP_TRY(hipMemcpy(t.data(), h->d_v2_ctovi.p + off, ne * sizeof(int16_t), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ne; ++i) ctovi[i] = t[i];
+    {   // the frame's message block, unpacked on the host into the reference's four arrays (v2.c: decoder.VtoC / VtoCindex / CtoV / CtoVindex)
+        const int nm = h->nm_alloc, R = ems_v2_rec_bytes(nm);
+        std::vector<uint8_t> blk((size_t)h->E * 2 * R);
+        HIP_TRY(hipMemcpy(blk.data(), h->d_v2_msg.p + (size_t)frame * blk.size(), blk.size(), hipMemcpyDeviceToHost));
+        for (int e = 0; e < h->E; ++e) {
+            const uint8_t *v = blk.data() + (size_t)e * 2 * R, *c = v + R;
+            for (int k = 0; k < nm; ++k) {
+                if (vtoc) memcpy(&vtoc[(size_t)e * nm + k], v + 4 * k, 4);
+                if (vtoci) vtoci[(size_t)e * nm + k] = v[EMS_V2_SYMS(nm) + k];
+                if (ctov) memcpy(&ctov[(size_t)e * nm + k], c + 4 * k, 4);
+                if (ctovi) { int16_t g; memcpy(&g, c + EMS_V2_SYMS(nm) + 2 * k, 2); ctovi[(size_t)e * nm + k] = g; }
+            }
+        }
     }
     if (app) HIP_TRY(hipMemcpy(app, h->d_v2_app.p + (size_t)frame * h->N * h->q, sizeof(float) * (size_t)h->N * h->q, hipMemcpyDeviceToHost));
     return EMS_OK;

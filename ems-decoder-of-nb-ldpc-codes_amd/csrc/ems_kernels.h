@@ -18,10 +18,10 @@ int ems_dual_max_waves(int dc);                              // waves per workgr
 size_t ems_dual_wave_lds_bytes(int q, int dc, int nm);
 size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves);
 hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
-                              float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st);
+                              float *likeS, uint8_t *msg, int rec, int *bad, hipStream_t st);
 hipError_t ems_launch_decode_v2(const EmsPlan &P, int B, hipStream_t st, const char **kname = nullptr);
-hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, float *vtoc, uint8_t *vtoci,
-                                   float *hint, int *bad, hipStream_t st);
+hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, uint8_t *msg, int rec,
+                                   int *bad, hipStream_t st);
 hipError_t ems_launch_sort_like_desc(const float *likeS, int N, int q, float *s_like, int *s_idx, hipStream_t st);
 
 // kname (optional) receives the launched kernel's name, template arguments included: a static string

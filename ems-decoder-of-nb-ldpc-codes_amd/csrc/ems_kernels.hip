@@ -1663,7 +1663,11 @@ __global__ void __launch_bounds__(OCC4 ? 256 : (LPE == 8 ? (Q >= 256 ? 12 : 16) 
                 process_cn<Q, LPE>(P, C, f, (cn & 0xFFFFFF) * C.dc, vn, lh, sweep == 0, t_i2b, t_b2i, dense, surv, lists, lens, picks, sched, oid, lane, true ST_ARGS);
             }
             // publish: all of this wave's global stores first (the fence waits for the whole wave's vmcnt)
+#if defined(EMS_ABL) && EMS_ABL == 7      // timing experiment (results wrong): the flag goes up without waiting for the stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
             if (lane == 0) __hip_atomic_store(&done[cur], (uint8_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             cur = nxt; cn = ncn; vn = nvn; lh = nlh; pred = npred; dcv = ndcv; e0v = ne0v;
         }
@@ -2149,12 +2153,15 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     const int t = DUAL ? (row & 3) : (rowact ? row : C.dc - 1);
     const int nm = C.nm, nmp = list_stride(nm), qm1 = Q - 1;
     const int edge = cn * C.dc + t;
-    // frame bases are wave-uniform (scalar registers); per-lane parts are 32-bit offsets
-    const size_t fe = (size_t)f * P.E * (size_t)nm;
-    float *const f_vtoc = P.v2_vtoc + fe, *const f_ctov = P.v2_ctov + fe;
-    uint8_t *const f_vtoci = P.v2_vtoci + fe;
-    int16_t *const f_ctovi = P.v2_ctovi + fe;
-    float *const f_hint = P.v2_hint + (size_t)f * P.E;
+    // frame base is wave-uniform (scalar registers); per-lane parts are 32-bit offsets.  Messages: one block of two records per edge
+    // (ems_plan.h): V->C at 2 e R, C->V at (2 e + 1) R
+    const unsigned R = (unsigned)ems_v2_rec_bytes(nm);     // (== P.v2_rec: the v2 flavour runs at its create-time nm; a constant in the specialised kernels)
+    uint8_t *const f_msg = P.v2_msg + (size_t)f * P.E * 2u * R;
+    // every access is f_msg (scalar registers) + ONE 32-bit per-lane byte offset: per-lane 64-bit pointers cost the kernel 13 spilled VGPRs
+    auto vrec = [&](int e) { return (unsigned)e * 2u * R; };           // byte offset of edge e's V->C record
+    auto crec = [&](int e) { return (unsigned)e * 2u * R + R; };       // ... and of its C->V record
+    auto ldf = [&](unsigned off) { return *reinterpret_cast<const float *>(f_msg + off); };
+    auto stf = [&](unsigned off, float v) { *reinterpret_cast<float *>(f_msg + off) = v; };
     float *drow = dense + row * Q;
 
     // the node's likelihood row is needed only by the variable-node update at the end; it is requested first so that
@@ -2165,16 +2172,22 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     // written by an earlier visitor, a predecessor of this task, so it is final now
     const int dst = DUAL ? dst_in : P.t_dst[task * C.dc + t];
     const bool lastv = rowact && (DUAL ? last_in : P.t_last[task * C.dc + t] != 0);
-    const float hint = f_hint[(unsigned)edge];               // search start of the selection at the end of the visit
+    const unsigned vin = vrec(edge);
+    const float hint = ldf(vin + EMS_V2_HINT(nm));           // search start of the selection at the end of the visit
     constexpr int NPRE = (EMS_MAX_NM + LPE - 1) / LPE;
     float ov[NPRE];
     int og[NPRE];
+    {
+        const unsigned oc = crec(dst);
 #pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-        const int k = rl + j * LPE;
-        const bool need = lastv && k < nm;
-        og[j] = need ? (int)f_ctovi[(unsigned)(dst * nm + k)] : -1;
-        ov[j] = need ? f_ctov[(unsigned)(dst * nm + k)] : 0.0f;
+        for (int j = 0; j < NPRE; ++j) {
+            og[j] = -1; ov[j] = 0.0f;
+            if (j * LPE >= nm) continue;
+            const int k = rl + j * LPE;
+            const bool need = lastv && k < nm;
+            og[j] = need ? (int)*reinterpret_cast<const int16_t *>(f_msg + (oc + (unsigned)(EMS_V2_SYMS(nm) + 2 * k))) : -1;
+            ov[j] = need ? ldf(oc + 4u * (unsigned)k) : 0.0f;
+        }
     }
 
     // ---- inputs: VtoC of my edges (v2.c:2125-2131), rotated by the edge coefficient (:1772-1784) ----
@@ -2182,8 +2195,8 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     for (int k = rl; k < nmp; k += LPE) {
         EmsEntry e = EmsEntry{__builtin_inff(), EMS_S_INVALID};
         if (k < nm) {
-            const float v = f_vtoc[(unsigned)(edge * nm + k)];
-            const int g = f_vtoci[(unsigned)(edge * nm + k)];
+            const float v = ldf(vin + 4u * (unsigned)k);
+            const int g = f_msg[vin + (unsigned)(EMS_V2_SYMS(nm) + k)];
             e = EmsEntry{v, (unsigned)t_i2b[gf_mul_log(g, lh, qm1)]};
         }
         if (DUAL || rowact) inl[k] = e;
@@ -2232,12 +2245,16 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     const EmsEntry *ol = lists + (DUAL ? dual_list_off(half, oid, nmp, 4) : oid * nmp);
     const int stp = (C.dc == 2) ? nm : lens[DUAL ? half * dual_nlists(4) + oid : oid];
 #endif
-    for (int k = rl; k < nm; k += LPE) {
-        const EmsEntry e = ol[k];
-        const bool valid = k < stp;
-        if (rowact) {
-            f_ctov[(unsigned)(edge * nm + k)] = e.v;
-            f_ctovi[(unsigned)(edge * nm + k)] = valid ? (int16_t)gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1) : (int16_t)-1;
+    {
+        const unsigned co = crec(edge);
+        for (int k = rl; k < nm; k += LPE) {
+            const EmsEntry e = ol[k];
+            const bool valid = k < stp;
+            if (rowact) {
+                stf(co + 4u * (unsigned)k, e.v);
+                *reinterpret_cast<int16_t *>(f_msg + (co + (unsigned)(EMS_V2_SYMS(nm) + 2 * k))) =
+                    valid ? (int16_t)gf_div_log((int)t_b2i[e.s & 0xFFu], lh, qm1) : (int16_t)-1;
+            }
         }
     }
 
@@ -2306,13 +2323,19 @@ __device__ __forceinline__ void process_cn_v2(const EmsPlan &P, const Cfg &C, in
     }
 #endif
     wave_lds_sync();
-    if (rowact && rl == 0) f_hint[(unsigned)edge] = T_sel;
+    // The threshold that worked goes into the V->C record written below, i.e. to the node's OTHER edge, whose next visit reads it with
+    // its message: a search start only -- the two rows of a node differ by one C->V message and want nearly the same threshold -- and
+    // the record of this visit's own edge is not written a second time (64 bytes of HBM write per edge and iteration)
+    if (rowact && rl == 0) stf(vrec(dst) + EMS_V2_HINT(nm), T_sel);
     const float last = -inl[nm - 1].v;                                        // :1545 normalisation to the nm-th value
-    for (int k = rl; k < nm; k += LPE) {
-        const EmsEntry e = inl[k];
-        if (rowact) {
-            f_vtoc[(unsigned)(dst * nm + k)] = (-e.v) - last;
-            f_vtoci[(unsigned)(dst * nm + k)] = (uint8_t)e.s;
+    {
+        const unsigned vo = vrec(dst);
+        for (int k = rl; k < nm; k += LPE) {
+            const EmsEntry e = inl[k];
+            if (rowact) {
+                stf(vo + 4u * (unsigned)k, (-e.v) - last);
+                f_msg[vo + (unsigned)(EMS_V2_SYMS(nm) + k)] = (uint8_t)e.s;
+            }
         }
     }
     wave_lds_sync();
@@ -2325,18 +2348,18 @@ __device__ __forceinline__ void app_decide_v2(const EmsPlan &P, const Cfg &C, in
     constexpr int LPE = 16;
     using G = Geo<Q, LPE>;
     const int nm = C.nm;
-    const size_t fe = (size_t)f * P.E * (size_t)nm;
-    const float *const f_ctov = P.v2_ctov + fe;
-    const int16_t *const f_ctovi = P.v2_ctovi + fe;
+    const unsigned R = (unsigned)ems_v2_rec_bytes(nm);
+    const uint8_t *const f_msg = P.v2_msg + (size_t)f * P.E * 2u * R;
     float a[G::EPL];
     load_row<Q, LPE>(P.v2_like + (size_t)f * P.N * Q + (unsigned)n * (unsigned)Q, rl, a);           // APP[n][index] = likelihood (:1907-1908)
     for (int tt = 0; tt < 2; ++tt) {                                          // its edges in interleaver order (:1910-1913)
         const int e = P.vn_edge[n * 2 + tt];
         fill_row<Q, LPE>(drow, rl, -C.offset);                                // TMP = -offset (:1899-1900)
         wave_lds_sync();
+        const unsigned co = (unsigned)e * 2u * R + R;                         // the edge's C->V record
         for (int k = rl; k < nm; k += LPE) {
-            const int g = f_ctovi[(unsigned)(e * nm + k)];
-            if (g >= 0) drow[g] = f_ctov[(unsigned)(e * nm + k)];               // :1901-1903 (every valid entry, no break)
+            const int g = *reinterpret_cast<const int16_t *>(f_msg + (co + (unsigned)(EMS_V2_SYMS(nm) + 2 * k)));
+            if (g >= 0) drow[g] = *reinterpret_cast<const float *>(f_msg + (co + 4u * (unsigned)k));   // :1901-1903 (every valid entry, no break)
         }
         wave_lds_sync();
         float c[G::EPL];
@@ -2611,7 +2634,7 @@ __global__ void __launch_bounds__(256, 3) k_decode_v2_dual(const EmsPlan P)
 // to both edges of the node as their first V->C messages (v2.c:2101-2113).  One 64-thread block per (frame, node); rank by
 // counting.  A selected value <= -1e5 (the reference would leave index -1 there) is reported through *bad.
 __global__ void k_v2_init_rows(const float *__restrict__ likeS, int N, int q, int nm, int E, const int *__restrict__ vn_edge,
-                               float *__restrict__ vtoc, uint8_t *__restrict__ vtoci, float *__restrict__ hint, int *__restrict__ bad)
+                               uint8_t *__restrict__ msg, int rec, int *__restrict__ bad)
 {
     __shared__ float v[256];
     const size_t fn = blockIdx.x;
@@ -2625,11 +2648,15 @@ __global__ void k_v2_init_rows(const float *__restrict__ likeS, int N, int q, in
         for (int j = 0; j < q; ++j) rank += (v[j] > vg || (v[j] == vg && j < g)) ? 1 : 0;
         if (rank < nm) {
             if (!(vg > -EMS_SENTINEL)) atomicOr(bad, 1);
-            vtoc[((size_t)f * E + e0) * nm + rank] = vg; vtoci[((size_t)f * E + e0) * nm + rank] = (uint8_t)g;
-            vtoc[((size_t)f * E + e1) * nm + rank] = vg; vtoci[((size_t)f * E + e1) * nm + rank] = (uint8_t)g;
+            for (int e : {e0, e1}) {                                    // the V->C record of both edges of the node
+                uint8_t *v = msg + ((size_t)f * E + e) * 2 * rec;
+                reinterpret_cast<float *>(v)[rank] = vg;
+                v[EMS_V2_SYMS(nm) + rank] = (uint8_t)g;
+            }
         }
     }
-    if (threadIdx.x == 0) { hint[(size_t)f * E + e0] = __builtin_inff(); hint[(size_t)f * E + e1] = __builtin_inff(); }
+    if (threadIdx.x == 0)
+        for (int e : {e0, e1}) *reinterpret_cast<float *>(msg + ((size_t)f * E + e) * 2 * rec + EMS_V2_HINT(nm)) = __builtin_inff();
 }
 
 // decoder.likelihood / likelihood_index of one frame (v2.c:1483-1497) from symbol-indexed rows: decreasing (value, symbol)
@@ -2652,8 +2679,8 @@ __global__ void k_sort_like_desc(const float *__restrict__ likeS, int q, float *
 
 // builds the symbol-indexed likelihood rows and the initial V->C messages (v2.c:2101-2113) from the sorted layout
 __global__ void k_v2_init(const float *__restrict__ like, const int *__restrict__ like_idx, int N, int q, int nm, int E,
-                          const int *__restrict__ vn_edge, float *__restrict__ likeS, float *__restrict__ vtoc,
-                          uint8_t *__restrict__ vtoci, float *__restrict__ hint, int *__restrict__ bad)
+                          const int *__restrict__ vn_edge, float *__restrict__ likeS, uint8_t *__restrict__ msg, int rec,
+                          int *__restrict__ bad)
 {
     const size_t fn = blockIdx.x;                         // (frame, node)
     const int f = (int)(fn / N), n = (int)(fn % N);
@@ -2666,9 +2693,10 @@ __global__ void k_v2_init(const float *__restrict__ like, const int *__restrict_
         const int tt = i / nm, k = i - tt * nm;
         const int e = vn_edge[n * 2 + tt];
         const int s = like_idx[fn * q + k];
-        vtoc[((size_t)f * E + e) * nm + k] = like[fn * q + k];
-        vtoci[((size_t)f * E + e) * nm + k] = (uint8_t)(s & 0xFF);
-        if (k == 0) hint[(size_t)f * E + e] = __builtin_inff();
+        uint8_t *v = msg + ((size_t)f * E + e) * 2 * rec;                   // the edge's V->C record
+        reinterpret_cast<float *>(v)[k] = like[fn * q + k];
+        v[EMS_V2_SYMS(nm) + k] = (uint8_t)(s & 0xFF);
+        if (k == 0) *reinterpret_cast<float *>(v + EMS_V2_HINT(nm)) = __builtin_inff();
     }
 }
 
@@ -3245,15 +3273,15 @@ hipError_t ems_debug_counters(unsigned long long *out8, int reset)
 
 // ---- v2 flavour launchers ----
 hipError_t ems_launch_v2_init(const float *like, const int *like_idx, int B, int N, int q, int nm, int E, const int *vn_edge,
-                              float *likeS, float *vtoc, uint8_t *vtoci, float *hint, int *bad, hipStream_t st)
+                              float *likeS, uint8_t *msg, int rec, int *bad, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_v2_init, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, like, like_idx, N, q, nm, E, vn_edge, likeS, vtoc, vtoci, hint, bad);
+    hipLaunchKernelGGL(k_v2_init, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, like, like_idx, N, q, nm, E, vn_edge, likeS, msg, rec, bad);
     return hipGetLastError();
 }
-hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, float *vtoc, uint8_t *vtoci,
-                                   float *hint, int *bad, hipStream_t st)
+hipError_t ems_launch_v2_init_rows(const float *likeS, int B, int N, int q, int nm, int E, const int *vn_edge, uint8_t *msg, int rec,
+                                   int *bad, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_v2_init_rows, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, likeS, N, q, nm, E, vn_edge, vtoc, vtoci, hint, bad);
+    hipLaunchKernelGGL(k_v2_init_rows, dim3((unsigned)((size_t)B * N)), dim3(64), 0, st, likeS, N, q, nm, E, vn_edge, msg, rec, bad);
     return hipGetLastError();
 }
 hipError_t ems_launch_sort_like_desc(const float *likeS, int N, int q, float *s_like, int *s_idx, hipStream_t st)

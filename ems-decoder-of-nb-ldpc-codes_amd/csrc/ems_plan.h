@@ -32,6 +32,20 @@ static inline int ems_rec_bytes(int nm) { return ((5 * nm + 9) + 15) & ~15; }
 #define EMS_REC_CNT(nm) (4 * (nm) + 8)
 #define EMS_REC_SYM(nm) (4 * (nm) + 9)
 
+// v2 flavour: the two messages of an edge as 64-byte-aligned records next to each other (round 3; five arrays of 20 / 40 / 80-byte
+// pieces per edge before: every piece cost whole 64-byte sectors, 1.25 x the algorithmic traffic).
+//   V->C record: float vals[nm] | uint8 sym[nm] (symbol index, always valid) | float hint (the edge's last selection threshold: a
+//                search start only) at EMS_V2_HINT
+//   C->V record: float vals[nm] (-1000 behind the valid prefix) | int16 sym[nm], -1 = none (v2.c:1854-1870)
+#if defined(__HIPCC__)
+#define EMS_HD __host__ __device__
+#else
+#define EMS_HD
+#endif
+EMS_HD static inline int ems_v2_rec_bytes(int nm) { return ((6 * nm > 5 * nm + 8 ? 6 * nm : 5 * nm + 8) + 63) & ~63; }
+#define EMS_V2_SYMS(nm) (4 * (nm))
+#define EMS_V2_HINT(nm) ((5 * (nm) + 3) & ~3)
+
 struct EmsPlan {
     // code
     int N, M, E, q, logq, dc;
@@ -81,11 +95,8 @@ struct EmsPlan {
     unsigned long long *stamps; // diagnostic builds only (EMS_STAMPS), else null
     // ---- v2 flavour (truncated messages both ways, max-is-best; EMS_HS_L-BubbleCheck_UBS_decoder_v2.c) ----
     const float *v2_like;   // [B][N][q]  likelihood of symbol g of node n (decoder.likelihood scattered by likelihood_index)
-    float *v2_vtoc;         // [B][E][nm] V->C values, edges in row order
-    uint8_t *v2_vtoci;      // [B][E][nm] their symbols (always valid)
-    float *v2_ctov;         // [B][E][nm] C->V values (-1000 where the symbol is -1)
-    int16_t *v2_ctovi;      // [B][E][nm] their symbols, -1 = none
-    float *v2_hint;         // [B][E]     last selection threshold of the edge's variable-node update (search start only)
+    uint8_t *v2_msg;        // [B][E][2][v2_rec] per edge (row order) its V->C record, then its C->V record (ems_v2_rec_bytes)
+    int v2_rec;             // bytes of one record
     float *v2_app;          // [B][N][q]  APP of the last iteration run (ComputeAPPLog)
     const int *t_dst;       // [M*dc]     per (task, edge): row-order id of the OTHER edge of its variable node (dv = 2)
     const int *vn_edge;     // [N][2]     NtoB: the two edges of a variable node in row order
