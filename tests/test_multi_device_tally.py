@@ -59,3 +59,18 @@ def test_c_harness_multi_device_path_with_rccl_on_one_gpu(pkg, kat, tmp_path, ca
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert b"RCCL all-reduce" in out.stderr
     assert _trace(out.stdout) == [list(t) for t in k["trace"]]
+
+
+@pytest.mark.gpu
+def test_c_harness_multi_device_path_with_the_device_side_source(pkg, tmp_path):
+    """EMS_GPU_SOURCE (frames generated in HBM from the counter-based stream, indexed by frame) through the multi-device loop: the
+    frames do not depend on which device or batch draws them, so `EMS_DEVICES=0` must print the trace of the single-device harness."""
+    args = [str(a) for a in (600, 10, os.path.join(MAT, "KN_N96_K48_GF64.txt"), 2.5, 16, 0.3, 32)]
+    os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
+    tr = []
+    for env in (dict(EMS_BATCH="64"), dict(EMS_BATCH="48", EMS_DEVICES="0")):
+        out = subprocess.run([pkg.SIM_PATH] + args, cwd=str(tmp_path), env=dict(os.environ, EMS_GPU_SOURCE="7", **env), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        tr.append(_trace(out.stdout))
+    assert len(tr[0]) > 100 and tr[0] == tr[1]
