@@ -342,9 +342,18 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     gold = load_bench_golden(workload)
     comparable = (gold is not None and not a.synthetic_zero_codeword and not ebn_overridden and gold["batch"] == B
                   and [gold["nm"], gold["NbOper"], gold["NbIterMax"]] == [nm, nop, itmax])
-    match = None
-    if rank == 0 and comparable:
-        match = local_counts[0] == gold["frames_errframes_biterrs_undetected_sumiter"]
+    match, ranks_checked = None, 0
+    if comparable:
+        # every rank checks ITS batch (frames [rank B, (rank + 1) B) of the stream) where the golden has it: rank 0 always, ranks 1.. of the
+        # headline workload when tests/golden/make_bench_golden.py --ranks has been run; the verdicts are combined over the ranks
+        per_rank = gold.get("ranks", {"0": gold["frames_errframes_biterrs_undetected_sumiter"]})
+        mine = per_rank.get(str(rank))
+        flags = torch.tensor([0 if mine is None else 1, 0 if (mine is None or local_counts[0] == mine) else 1], dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(flags)                                  # [ranks that had a golden, ranks whose counters differ]
+        ranks_checked, bad = int(flags[0].item()), int(flags[1].item())
+        if "0" in per_rank:
+            match = bad == 0
 
     # ---- side figure (never `value`): BASELINE.json configs[3] to the letter, the same code at batch = 256 (one frame per CU) ----
     b256 = None
@@ -421,7 +430,7 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     res = {
         "value": round(world * B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "data": data,
         "workload": "%s nm=%d NbIterMax=%d (%d sweeps) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, sweeps, off, nop),
-        "batch_per_gpu": B, "counters": tot, "counters_match_golden": match,
+        "batch_per_gpu": B, "counters": tot, "counters_match_golden": match, "golden_ranks_checked": ranks_checked,
         "roofline": {"bound": "hbm",
                      "kernel": "%s (persistent, %s, %d waves per workgroup, %d frames per launch on %d CUs)"
                                % (kernel, "1 wave per 2 frames" if "twin" in kernel else "1 workgroup per frame", wg_waves, B, n_cu),
@@ -510,9 +519,11 @@ def main():
                        "batch_per_gpu": B, "sharding": "independent frames, contiguous batches per rank",
                        "collective": "all-reduce of 5 int64 error counters per step" if world > 1 else "none",
                        "frames_errframes_biterrs_undetected_sumiter": main_res["counters"]},
-            # rank 0's counters of the timed run == the CPU oracle's on the same frames (tests/golden/bench_counters.json); null when
-            # the run is not the committed workload (other batch, --synthetic-zero-codeword, EMS_BENCH_EBN)
+            # the counters of the timed run == the CPU oracle's on the same frames (tests/golden/bench_counters.json), rank by rank for the
+            # ranks the golden covers (`golden_ranks_checked`); null when the run is not the committed workload (other batch,
+            # --synthetic-zero-codeword, EMS_BENCH_EBN)
             "counters_match_golden": main_res["counters_match_golden"],
+            "golden_ranks_checked": main_res["golden_ranks_checked"],
             "roofline": main_res["roofline"],
             "host_setup_s": main_res["host_setup_s"],
         }

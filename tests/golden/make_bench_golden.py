@@ -11,6 +11,7 @@ after the last sweep; per workload the five counters of the harness (frames, err
 sum of iterations; NB_LDPC.c:474-497) that bench.py compares its timed run with (`counters_match_golden`).
 
     python tests/golden/make_bench_golden.py [gf256] [gf16] [n96]     (run from the repo root; gf256 takes ~15 min on 8 cores)
+    python tests/golden/make_bench_golden.py --ranks 1 2 ... 7          (the headline counters of ranks 1.. of a multi-GPU bench)
 """
 import json
 import os
@@ -31,11 +32,26 @@ WORKLOADS = {   # name: (matrix, nm, NbOper, offset, NbIterMax, Eb/N0, frames) -
 }
 
 
-def generate(name, threads):
+LCG_A, LCG_C, LCG_MASK = 0x5DEECE66D, 0xB, (1 << 48) - 1
+
+
+def lcg_jump(x0, n):
+    """State of glibc's drand48 LCG after n draws from x0 (the affine map raised to the n-th power)."""
+    a, c, ba, bc = 1, 0, LCG_A, LCG_C
+    while n > 0:
+        if n & 1:
+            a, c = (ba * a) & LCG_MASK, (ba * c + bc) & LCG_MASK
+        ba, bc = (ba * ba) & LCG_MASK, (ba * bc + bc) & LCG_MASK
+        n >>= 1
+    return (a * x0 + c) & LCG_MASK
+
+
+def generate(name, threads, rank=0):
     mat, nm, nop, off, itmax, ebn, F = WORKLOADS[name]
     o = orc.Oracle(os.path.join(ROOT, "tests", "golden", "matrices", mat))
     sigma = o.sigma(ebn)
-    rng = orc.Rng(0)
+    # rank r of a multi-GPU bench owns frames [r F, (r + 1) F) of the stream: K logq source draws + 2 N logq channel draws per frame
+    rng = orc.Rng(lcg_jump(0, rank * F * (o.K * o.logq + 2 * o.N * o.logq)))
     frames = [o.draw_frame(rng, sigma) for _ in range(F)]          # the reference's stream, frame after frame (NB_LDPC.c:255-261)
 
     def one(i):
@@ -52,8 +68,24 @@ def generate(name, threads):
     return rec, counters
 
 
+def add_ranks(ranks, threads):
+    """bench_counters.json["gf256"]["ranks"][r]: the counters of rank r's batch of a `bench.py --gpus N` run (r >= 1; counters only)."""
+    cj = os.path.join(ROOT, "tests", "golden", "bench_counters.json")
+    counters = json.load(open(cj))
+    rk = counters["gf256"].setdefault("ranks", {"0": counters["gf256"]["frames_errframes_biterrs_undetected_sumiter"]})
+    for r in ranks:
+        if str(r) in rk:
+            continue
+        _rec, cnt = generate("gf256", threads, rank=r)
+        rk[str(r)] = cnt
+        json.dump(counters, open(cj, "w"), indent=1)
+
+
 if __name__ == "__main__":
     orc.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "--ranks":              # e.g. --ranks 1 2 3 4 5 6 7 (18 minutes of 8 cores each)
+        add_ranks([int(x) for x in sys.argv[2:]], int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count() or 8))))
+        sys.exit(0)
     which = sys.argv[1:] or list(WORKLOADS)
     threads = int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count() or 8)))
     gdir = os.path.join(ROOT, "tests", "golden")
