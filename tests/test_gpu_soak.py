@@ -22,7 +22,7 @@ def v2(orc):
 
 CASES = [  # name, nm, NbOper, offset, NbIterMax, Eb/N0 points, batches (each selects another kernel shape)
     ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, (1.45, 1.6, 1.75, 1.9), (256, 640, 1024, 1536)),
-    ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, (2.6, 2.9, 3.1), (256,)),
+    ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, (1.8, 2.3, 2.6, 2.9, 3.1), (256,)),     # 1.8 / 2.3 dB: frames that run all 29 sweeps
     ("N96_K48_GF64", 16, 32, 0.3, 30, (0.0, 2.0, 3.5), (512, 8192)),
 ]
 
