@@ -276,6 +276,8 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)
     dec = pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False)
+    # developer knob: a single process decodes the batch rank r of a multi-GPU run would own (checks the ranks' goldens on one GPU)
+    frames_of = int(os.environ.get("EMS_BENCH_FRAMES_OF_RANK", rank))
 
     # ---- synthetic inputs, staged in HBM before the timed region ----
     t_setup = time.time()
@@ -288,7 +290,7 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     else:
         with c_stdout_to_stderr():
             src = harness.FrameSource(matrix, nm)
-            src.position(rank * B)                  # rank r owns frames [r*B, (r+1)*B) of the stream
+            src.position(frames_of * B)             # rank r owns frames [r*B, (r+1)*B) of the stream
             cws, noisy, sigma = src.draw(B, ebn)
             src.close()
         data = "synthetic: random codewords + BPSK/AWGN from the reference harness' drand48 stream, Eb/N0 %.1f dB" % ebn
@@ -347,12 +349,12 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
         # every rank checks ITS batch (frames [rank B, (rank + 1) B) of the stream) where the golden has it: rank 0 always, ranks 1.. of the
         # headline workload when tests/golden/make_bench_golden.py --ranks has been run; the verdicts are combined over the ranks
         per_rank = gold.get("ranks", {"0": gold["frames_errframes_biterrs_undetected_sumiter"]})
-        mine = per_rank.get(str(rank))
+        mine = per_rank.get(str(frames_of))
         flags = torch.tensor([0 if mine is None else 1, 0 if (mine is None or local_counts[0] == mine) else 1], dtype=torch.int64, device="cuda")
         if dist is not None:
             dist.all_reduce(flags)                                  # [ranks that had a golden, ranks whose counters differ]
         ranks_checked, bad = int(flags[0].item()), int(flags[1].item())
-        if "0" in per_rank:
+        if ranks_checked > 0:
             match = bad == 0
 
     # ---- side figure (never `value`): BASELINE.json configs[3] to the letter, the same code at batch = 256 (one frame per CU) ----
