@@ -872,6 +872,19 @@ __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int
     for (int i = tid; i < (dc - 2) * 8; i += nthreads) sched[i] = cn_task(dc, list_stride(nm), (i >> 3) + 1, i & 7);
 }
 
+// The merge form of a GF(16) / nm = 8 stage whose first-occurrence form met a tie or the NbOper limit (2 % of the wave-stages), as a
+// REAL call: inlined, the merge loop and its post-pass pushed the whole kernel from 115 VGPRs to the 128 cap plus 7-11 spilled ones and
+// cost the common path 15 % (33.9 against 40.1 ms per launch with the redo compiled out).  LDS pointers travel as address-space-3
+// pointers, so that the callee addresses LDS directly instead of through flat instructions.
+#define EMS_LDS(T) __attribute__((address_space(3))) T *
+__device__ __attribute__((noinline)) void es_redo_q16(EMS_LDS(EmsEntry) lists, EMS_LDS(int) lens, EMS_LDS(unsigned) tbl, EMS_LDS(uint8_t) picks,
+                                                      int lane, uint2 task, int nbOper, int T1, bool wide)
+{
+    ST_DUMMY
+    if (wide) es_stage_fast<16>((EmsEntry *)lists, (int *)lens, (unsigned *)tbl, (uint8_t *)picks, 16, lane, task, 8, nbOper, T1 ST_ARGS);
+    else es_stage_fast<8>((EmsEntry *)lists, (int *)lens, (unsigned *)tbl, (uint8_t *)picks, 16, lane, task, 8, nbOper, T1 ST_ARGS);
+}
+
 // TL lanes per elementary-step task: 16 (one visit per wave; the literal form uses 8 of them twice over) or 8 (two visits)
 // bins: the 16-word-per-task tables of es_stage_q16 (all +inf), or null: GF(16) / nm = 8 visits then take the first-occurrence form
 template <int TL = 16>
@@ -901,9 +914,14 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
             const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
             STAMP(9);
             DBG_ADD(3, 1);
-            if (__ballot(redo) == 0ull) { wave_lds_sync(); continue; }
+            if (__builtin_expect(__ballot(redo) == 0ull, 1)) { wave_lds_sync(); continue; }
             DBG_ADD(5, 1);
             wave_lds_sync();                                        // (rare) some task of the stage needs the exact merge: the whole stage again
+            if (TL == 8) {
+                es_redo_q16((EMS_LDS(EmsEntry))lists, (EMS_LDS(int))lens, (EMS_LDS(unsigned))tbl, (EMS_LDS(uint8_t))picks, lane, task, C.nbOper, C.T1, wide);
+                wave_lds_sync();
+                continue;
+            }
         }
         if (fast && wide) es_stage_fast<16>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
