@@ -786,6 +786,9 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     }
     if constexpr (NB == 2) *reinterpret_cast<uint2 *>(bins + 2 * p) = uint2{Q16_INF, Q16_INF};
     else bins[p] = Q16_INF;
+#if defined(EMS_ABLQ) && EMS_ABLQ == 2     // (ablation: no detection either -- the tests above are dead code then)
+    return false;
+#endif
     return has && bad;
 }
 
@@ -914,6 +917,10 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
             const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
             STAMP(9);
             DBG_ADD(3, 1);
+#ifdef EMS_ABLQ      // ablation builds of the GF(16) stage (timing experiments; results wrong in the 0.25 % of tasks that need the redo):
+            if (redo) picks[0] = 1;                                 // 1 = detection kept alive, never acted upon (2: see es_stage_q16)
+            wave_lds_sync(); continue;
+#endif
             if (__builtin_expect(__ballot(redo) == 0ull, 1)) { wave_lds_sync(); continue; }
             DBG_ADD(5, 1);
             wave_lds_sync();                                        // (rare) some task of the stage needs the exact merge: the whole stage again
