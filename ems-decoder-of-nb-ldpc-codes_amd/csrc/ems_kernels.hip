@@ -644,6 +644,15 @@ template <int N> __device__ __forceinline__ int count_above(const float (&x)[N],
     return __popc(a);
 }
 
+// number of elements of x[0..N) that are < T (T finite; +inf elements never count): sign bits of x - T
+template <int N> __device__ __forceinline__ int count_below(const float (&x)[N], float T)
+{
+    unsigned a = 0u;
+#pragma unroll
+    for (int e = 0; e < N; ++e) a = __builtin_amdgcn_alignbit(a, __float_as_uint(x[e] - T), 31);
+    return __popc(a);
+}
+
 template <int TL>
 __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigned *bins_base, int lane, uint2 task, int nbOper)
 {
@@ -755,7 +764,7 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     pack = redT_sumi<TL>(pack);
     const int D = pack & 31, rsum = (pack >> 5) & 255;
     bool bad = 2 * rsum != D * (D - 1);                    // two first occurrences with the same value: their order is the competitors'
-    const int S = min(D, 8);
+    int S = min(D, 8);
     unsigned x7 = 0u;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -770,7 +779,7 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
         for (int j = 0; j < NS; ++j) cnt += (__float_as_uint(v[j]) == kstop) ? 256 : 0;
     }
     cnt = redT_sumi<TL>(cnt);
-    bad = bad || (cnt & 255) > nbOper;                                           // :472 would have cut the scan short
+    const bool ovf = (cnt & 255) > nbOper;                                       // :472 cuts the scan short (handled below)
     // Another cell with the value K that ends the scan, when the scan gets that far: the order of the two would matter.  Rows of 16
     // lanes count the cells with that value.  Rows of 8 read it off the bins: a tie matters only when the other cell is the first
     // occurrence of ANOTHER symbol (a repeated symbol changes nothing, the same symbol gives the same entry either way) -- then its
@@ -778,6 +787,38 @@ __device__ __forceinline__ bool es_stage_q16(EmsEntry *lists, int *lens, unsigne
     // is left is "some valid bin holds K and no boundary cell at K is a first occurrence", plus two boundary cells at K.
     if constexpr (TL == 16) bad = bad || (kstop <= xcut && (cnt >> 8) > 1);
     else bad = bad || (kstop <= xcut && (((pack >> 23) & 31) > 1 || (((pack >> 13) & 31) >= 1 && ((pack >> 18) & 31) == 0)));
+    // ---- the scan cut by NbOper (:472; 0.35 % of the tasks, one wave-stage in fifty): it ends on its NbOper-th cell, before any other
+    //      stop, so what it emits are the first occurrences with at most NbOper cells up to and including their own -- a prefix of the
+    //      rank order.  Thresholds = the entries just stored; per threshold one count over the task's cells, eight counts through
+    //      two butterflies.  A cell with the same value as the first entry left out could have come before or after the cut when
+    //      fewer than NbOper cells are strictly below it: that task goes to the merge form. ----
+    if (__builtin_expect(__ballot(has && ovf && !bad) != 0ull, 0)) {
+        wave_lds_sync();
+        const uint4 *o4 = static_cast<const uint4 *>(__builtin_assume_aligned(out, 16));
+        const uint4 t01 = o4[0], t23 = o4[1], t45 = o4[2], t67 = o4[3];
+        const unsigned thr[8] = {t01.x, t01.z, t23.x, t23.z, t45.x, t45.z, t67.x, t67.z};
+        int lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lo += (NS - count_above(v, __uint_as_float(thr[r]))) << (8 * r);
+            hi += (NS - count_above(v, __uint_as_float(thr[4 + r]))) << (8 * r);
+        }
+        lo = redT_sumi<TL>(lo);
+        hi = redT_sumi<TL>(hi);
+        int S2 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) S2 += (r < S && (((r < 4 ? lo : hi) >> (8 * (r & 3))) & 255) <= nbOper) ? 1 : 0;
+        unsigned tS = thr[7];
+#pragma unroll
+        for (int r = 6; r >= 0; --r) tS = (S2 == r) ? thr[r] : tS;
+        const int below = redT_sumi<TL>(count_below(v, __uint_as_float(tS)));
+        if (ovf && !bad) {
+            bad = S2 < S && below < nbOper;
+            S = S2;
+        }
+    } else {
+        bad = bad || ovf;
+    }
     // ---- tail, pads, length; bins back to +inf ----
     if (has) {
         if (p < 8 && p >= S) out[p] = EmsEntry{EMS_SENTINEL, EMS_S_INVALID};     // :370-374 shows through behind the S entries
@@ -875,10 +916,10 @@ __device__ __forceinline__ void cn_sched_build(uint2 *sched, int dc, int nm, int
     for (int i = tid; i < (dc - 2) * 8; i += nthreads) sched[i] = cn_task(dc, list_stride(nm), (i >> 3) + 1, i & 7);
 }
 
-// The merge form of a GF(16) / nm = 8 stage whose first-occurrence form met a tie or the NbOper limit (2 % of the wave-stages), as a
-// REAL call: inlined, the merge loop and its post-pass pushed the whole kernel from 115 VGPRs to the 128 cap plus 7-11 spilled ones and
-// cost the common path 15 % (33.9 against 40.1 ms per launch with the redo compiled out).  LDS pointers travel as address-space-3
-// pointers, so that the callee addresses LDS directly instead of through flat instructions.
+// The merge form of a GF(16) / nm = 8 stage of a two-visit wave, for the stages of a visit from the one whose first-occurrence form met
+// a tie (see cn_core), as a REAL call: inlined, the merge loop and its post-pass pushed the whole kernel from 115 VGPRs to the 128 cap
+// plus 7-11 spilled ones and cost the common path 15 % (33.9 against 40.1 ms per launch with the redo compiled out).  LDS pointers
+// travel as address-space-3 pointers, so that the callee addresses LDS directly instead of through flat instructions.
 #define EMS_LDS(T) __attribute__((address_space(3))) T *
 __device__ __attribute__((noinline)) void es_redo_q16(EMS_LDS(EmsEntry) lists, EMS_LDS(int) lens, EMS_LDS(unsigned) tbl, EMS_LDS(uint8_t) picks,
                                                       int lane, uint2 task, int nbOper, int T1, bool wide)
@@ -901,6 +942,35 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
         if (TL == 16 && C.onfly) return cn_task(C.dc, list_stride(C.nm), t, lane / 16);   // this visit's own degree
         return sched[(t - 1) * 8 + (wide ? lane / 16 : lane / TL)];
     };
+    int t0 = 1;
+    if (TL == 8 && q16) {
+        // Two-visit waves, GF(16) / nm = 8: the stages in the first-occurrence form, in a loop of their own.  A stage that needs the merge
+        // form (two first occurrences with the same value: 5 wave-stages in 100 000) leaves the loop, and the REST of the visit's stages
+        // run in the merge form through a real call -- with the call inside the loop the common path paid 3 % for its presence.
+        for (; t0 <= C.nsteps; ++t0) {
+            const bool wide = dual_stage_wide(C.dc, t0);
+            const uint2 task = task_of(t0);
+            STAMP(8);
+            const bool redo = wide ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
+            STAMP(9);
+            DBG_ADD(3, 1);
+#ifdef EMS_ABLQ      // ablation builds of the GF(16) stage (timing experiments; results wrong in the tasks that need the redo):
+            if (redo) picks[0] = 1;                                 // 1 = detection kept alive, never acted upon (2: see es_stage_q16)
+            wave_lds_sync();
+#else
+            const bool again = __ballot(redo) != 0ull;
+            wave_lds_sync();
+            if (__builtin_expect(again, 0)) break;
+#endif
+        }
+        for (; t0 <= C.nsteps; ++t0) {                              // (rare) from the stage that asked for it to the end of the visit
+            DBG_ADD(5, 1);
+            es_redo_q16((EMS_LDS(EmsEntry))lists, (EMS_LDS(int))lens, (EMS_LDS(unsigned))tbl, (EMS_LDS(uint8_t))picks, lane, task_of(t0), C.nbOper, C.T1,
+                        dual_stage_wide(C.dc, t0));
+            wave_lds_sync();
+        }
+        return;
+    }
 #ifdef EMS_TASK_PREFETCH
     uint2 task_next = task_of(1);
 #endif
@@ -914,21 +984,12 @@ __device__ __forceinline__ void cn_core(const Cfg &C, EmsEntry *lists, int *lens
 #endif
         if (q16) {
             STAMP(8);
-            const bool redo = (wide || TL == 16) ? es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper) : es_stage_q16<8>(lists, lens, bins, lane, task, C.nbOper);
+            const bool redo = es_stage_q16<16>(lists, lens, bins, lane, task, C.nbOper);
             STAMP(9);
             DBG_ADD(3, 1);
-#ifdef EMS_ABLQ      // ablation builds of the GF(16) stage (timing experiments; results wrong in the 0.25 % of tasks that need the redo):
-            if (redo) picks[0] = 1;                                 // 1 = detection kept alive, never acted upon (2: see es_stage_q16)
-            wave_lds_sync(); continue;
-#endif
-            if (__builtin_expect(__ballot(redo) == 0ull, 1)) { wave_lds_sync(); continue; }
+            if (__ballot(redo) == 0ull) { wave_lds_sync(); continue; }
             DBG_ADD(5, 1);
             wave_lds_sync();                                        // (rare) some task of the stage needs the exact merge: the whole stage again
-            if (TL == 8) {
-                es_redo_q16((EMS_LDS(EmsEntry))lists, (EMS_LDS(int))lens, (EMS_LDS(unsigned))tbl, (EMS_LDS(uint8_t))picks, lane, task, C.nbOper, C.T1, wide);
-                wave_lds_sync();
-                continue;
-            }
         }
         if (fast && wide) es_stage_fast<16>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);
         else if (fast) es_stage_fast<TL>(lists, lens, tbl, picks, C.q, lane, task, C.nm, C.nbOper, C.T1 ST_ARGS);

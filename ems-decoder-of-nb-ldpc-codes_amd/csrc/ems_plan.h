@@ -26,7 +26,10 @@ struct EmsEntry {
 // [4nm+4,4nm+8) float hint (the selection threshold that worked for this edge in the previous sweep:
 // a search start only, never part of the result); [4nm+8] uint8 cnt; [4nm+9, 5nm+9) uint8 sym[nm]
 // (symbol INDEX after the inverse rotation); padded to a multiple of 16.
-static inline int ems_rec_bytes(int nm) { return ((5 * nm + 9) + 15) & ~15; }
+#ifndef EMS_REC_ALIGN
+#define EMS_REC_ALIGN 16
+#endif
+static inline int ems_rec_bytes(int nm) { return ((5 * nm + 9) + EMS_REC_ALIGN - 1) & ~(EMS_REC_ALIGN - 1); }
 #define EMS_REC_DFLT(nm) (4 * (nm))
 #define EMS_REC_HINT(nm) (4 * (nm) + 4)
 #define EMS_REC_CNT(nm) (4 * (nm) + 8)

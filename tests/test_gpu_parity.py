@@ -300,6 +300,9 @@ def test_decode_gf16_state_and_fixed_work(pkg, orc):
     non-converging fixed-work run."""
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 2, state=True)
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 6, 0.0, 2, state=True, early_exit=False)
+    # NbOper = nm + 3 (the scan is cut short in one task of eight: the closed form of that cut in the 8-lane stages) and 3 nm (never)
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 11, 0.3, 5, 0.0, 2, state=True, early_exit=False)
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 24, 0.3, 4, 0.0, 2, state=True, early_exit=False)
 
 
 def test_decode_gf256_vs_oracle(pkg, orc):
