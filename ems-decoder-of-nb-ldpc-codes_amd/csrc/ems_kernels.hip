@@ -554,7 +554,11 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     es_merge<false>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
     STAMP(9);
     DBG_ADD(3, 1);
+#if defined(EMS_ABL) && EMS_ABL == 8      // ablation (results wrong where it matters): no tie redo, no long continuation, no selection fallback
+    if (false) {
+#else
     if (__ballot(has && red8_sumi(pos - pos0) != T1) != 0ull) {   // a tie somewhere: redo with the exact rule
+#endif
         DBG_ADD(5, 1);
         init();
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, 0, T1);
@@ -566,7 +570,11 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
     else if (TL == 8 && T1 <= 24) done = es_post<3, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
     else if (TL == 8 && T1 <= 32) done = es_post<4, 0, TL>(in1, in2, out, tbl, picks, dummy, q, p16, gbase16, p, gbase, has, T1, nm, nbOper, S, hv, pos, fxv, mvy, Td);
     else done = es_post_rt<0, TL>(in1, in2, out, tbl, picks, q, p16, gbase16, has, T1, nm, nbOper, S);
+#if defined(EMS_ABL) && EMS_ABL == 8
+    if (false) {
+#else
     if (__ballot(has && !done) != 0ull) {
+#endif
         // rare: neither nm outputs nor a stop within the first nm+3 (+8) picks -> merge on up to nbOper
         DBG_ADD(6, 1);
         es_merge<true>(hv, pos, fxv, mvy, picks, dummy, p, gbase, Td, nbOper);
@@ -595,8 +603,9 @@ __device__ __forceinline__ void es_stage_fast(EmsEntry *lists, int *lens, unsign
 //     emitted iff its bin is <= K;
 //   * nm outputs (:502): the first 8 bins in rank order;
 //   * nbOper (:472): the scan up to the last emitted entry (or K) visits N = #{cells <= that value} cells; if N > nbOper the
-//     reference stops early -- such a task (0.2 % of them at NbOper = 16) is redone by the merge form;
-// and so is a task where the order of two equal values could matter: two bins with the same value (their ranks then do not
+//     reference stops on its nbOper-th cell (0.35 % of the tasks at NbOper = 16) -- what it has emitted by then is the prefix of
+//     the rank order whose entries have at most nbOper cells up to and including their own (block at the end of the function);
+// a task where the order of two equal values could matter is redone by the merge form: two bins with the same value (their ranks then do not
 // add up), or a second cell with the value K when the scan gets that far.  Equal values with the same symbol, and ties among
 // cells that are not first occurrences, change nothing.  Values are compared as floats by the sign of their difference
 // (non-negative, no NaN among valid ones) or as bit patterns.
@@ -1512,7 +1521,11 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
     for (int k = rl; k < nm + 2; k += LPE) inl[k] = EmsEntry{k < nm ? (float)k * 0.5f + mvc[0] * 1e-9f : __builtin_inff(), k < nm ? (unsigned)((k * 7 + row * 3 + (lh & 15)) & (Q - 1)) : EMS_S_INVALID};
     if (false) {
 #else
-    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow, sw)) {
+    if (!select_threshold<Q, LPE>(mvc, surv + row * surv_stride(LPE), inl, rl, lane, nm, lh, t_i2b, rowact, big, hint, T_sel, drow, sw)
+#if defined(EMS_ABL) && EMS_ABL == 8
+        && false
+#endif
+       ) {
 #endif
         // literal path (huge tie groups): nm rounds of first-minimum, then normalise + rotate
         select_rounds<Q, LPE>(mvc, inl, rl, nm);
@@ -1558,7 +1571,11 @@ __device__ __forceinline__ void process_cn(const EmsPlan &P, const Cfg &C, int f
 #if defined(EMS_ABL) && (EMS_ABL == 1 || EMS_ABL == 5)      // ablation builds (make ablation; timing experiments, results wrong by construction): no elementary steps, the output list of an edge is its input list
     (void)tbl; (void)bins;
 #else
+#if defined(EMS_ABL) && EMS_ABL == 8
+    cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, false, bins ST_ARGS);
+#else
     cn_core<DUAL ? 8 : 16>(C, lists, lens, tbl, picks, sched, lane, __ballot(big) != 0ull, bins ST_ARGS);
+#endif
 #endif
 
     STAMP(2);
