@@ -305,6 +305,14 @@ def test_decode_gf16_state_and_fixed_work(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 24, 0.3, 4, 0.0, 2, state=True, early_exit=False)
 
 
+@pytest.mark.parametrize("nop", [12, 13, 14, 15, 17, 20, 32])
+def test_decode_gf16_nboper_sweep_vs_oracle(pkg, orc, nop):
+    """The GF(16) two-visits-per-wave kernel under every NbOper around the message size: the closed form of the scan cut by NbOper
+    (es_stage_q16: the prefix of the rank order with at most NbOper cells) against the oracle's literal loop -- one non-converging
+    frame, four sweeps, full APP / C->V state."""
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, nop, 0.3, 5, 0.0, 1, state=True, early_exit=False)
+
+
 def test_decode_gf256_vs_oracle(pkg, orc):
     it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.6, 4)
     assert list(it) == [30, 30, 30, 25]                # K4: frame 4 converges in 25 sweeps
