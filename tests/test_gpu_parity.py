@@ -395,6 +395,29 @@ def test_saturated_and_negative_llrs(pkg, orc):
     dec.close()
 
 
+def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
+    """GF(16) / nm = 8 on the two-visits-per-wave kernel with LLRs on a coarse grid: equal first occurrences in nearly every elementary
+    step, i.e. the stage leaves the first-occurrence loop and the rest of the visit runs in the merge form through the out-of-line
+    call (5 wave-stages in 100 000 on the bench workload, nearly all of them here); half-integer and integer grids, full state."""
+    path = os.path.join(MAT, "Ahmed_64800_R34_GF16")
+    o = orc.Oracle(path)
+    rs = np.random.RandomState(5)
+    llr = (rs.rand(3, o.N, o.q) * 14).astype(np.float32)
+    llr[0] = np.round(llr[0])                       # integers: ties everywhere
+    llr[1] = np.round(llr[1] * 2) / 2               # half-integers
+    llr[2, ::2] = np.round(llr[2, ::2])             # every other node coarse, the rest continuous
+    dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 4, max_batch=3, early_exit=False)
+    dec.load_llr(llr)
+    dec.decode(3)
+    assert dec.last_kernel == "k_decode_dual<16, 8, 8>"
+    d, it, sy = dec.results(3)
+    for b in range(3):
+        ref = o.decode(llr[b], 8, 16, 0.3, 4, early_exit=False, want_state=True)
+        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"]
+        assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes()
+    dec.close()
+
+
 def test_batch_position_invariance_and_repeatability(pkg, orc):
     path = os.path.join(MAT, "N96_K48_GF64")
     o = orc.Oracle(path)
