@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- decoded frames/s of the MI355X EMS NB-LDPC hot path on the headline configuration.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 works two ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment: this process IS a rank), or from a plain shell -- the process then only starts N fresh rank processes of
+itself (launch_ranks below; it never imports torch or touches HIP), relays rank 0's JSON line, and exits non-zero as soon
+as any rank fails or the run exceeds EMS_BENCH_LAUNCH_TIMEOUT seconds (default 1500), after killing every rank it started.
 
 A "step" is one pass of the hot path over one batch of synthetic frames per GPU: GF(q) channel-LLR
 init -> 29 layered EMS sweeps with per-sweep hard decision + syndrome -> bit-error count, inputs
@@ -356,6 +361,8 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
         ranks_checked, bad = int(flags[0].item()), int(flags[1].item())
         if ranks_checked > 0:
             match = bad == 0
+        if "ranks" in gold:                                         # (the headline workload: the golden covers ranks 0..7)
+            check_ranks_against_golden(world, ranks_checked, bad)
 
     # ---- side figure (never `value`): BASELINE.json configs[3] to the letter, the same code at batch = 256 (one frame per CU) ----
     b256 = None
@@ -458,6 +465,138 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell (no RANK / WORLD_SIZE): start N FRESH rank processes of this script, one per
+    GPU, with the rendezvous variables torch.distributed expects.  This parent never imports torch and never touches HIP (a process
+    that has initialised the GPU must not be replaced or forked on this pool); it relays rank 0's JSON line and fails loudly:
+    the first rank that exits non-zero, or the deadline, kills every rank (each in its own session, by the exact process
+    groups started here) and the parent exits non-zero.  The harness counters and the stop the all-reduce serves:
+    NB_LDPC.c:491-506."""
+    import signal
+    import subprocess
+    import threading
+    timeout = float(os.environ.get("EMS_BENCH_LAUNCH_TIMEOUT", "1500"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(l.decode("utf-8", "replace") for l in procs[0].stdout), daemon=True)
+    reader.start()
+
+    def kill_all():
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, sig)                    # its own session: pgid == pid, nothing else is in it
+                    except ProcessLookupError:
+                        pass
+            t_end = time.time() + grace
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+
+    deadline = time.time() + timeout
+    why = None
+    try:
+        while why is None:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                why = "rank %d exited with code %d" % bad[0]
+            elif all(rc == 0 for rc in rcs):
+                break
+            elif time.time() > deadline:
+                why = "no result after %.0f s (EMS_BENCH_LAUNCH_TIMEOUT)" % timeout
+            else:
+                time.sleep(0.1)
+    except BaseException:
+        kill_all()
+        raise
+    if why is not None:
+        kill_all()
+        sys.stderr.write("bench.py --gpus %d: %s; every rank was stopped\n" % (n, why))
+        raise SystemExit(1)
+    reader.join(timeout=10)
+    js = [l for l in lines if l.lstrip().startswith("{")]
+    if len(js) != 1:
+        sys.stderr.write("bench.py --gpus %d: rank 0 printed %d JSON lines instead of one\n" % (n, len(js)))
+        raise SystemExit(1)
+    sys.stdout.write(js[0] if js[0].endswith("\n") else js[0] + "\n")
+    sys.stdout.flush()
+
+
+def bench_fake(a, rank, world):
+    """Launcher rehearsal (EMS_BENCH_FAKE_DECODE=1; tests/test_bench_launcher.py): the rank skeleton of run_decode_workload -- process
+    group, barrier-fenced timed steps, the per-step all-reduce of the five counters, the per-rank golden check -- on the gloo backend
+    with a stand-in for the decode that just reports the golden counters of the rank's frame range.  Nothing here is a measurement:
+    the line says so in `metric`, `data` and `config`, and carries value 0."""
+    import torch
+    import torch.distributed as dist
+    die, hang, corrupt = (int(os.environ.get("EMS_BENCH_FAKE_" + k, "-1")) for k in ("DIE_RANK", "HANG_RANK", "CORRUPT_RANK"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (a.gpus, dist.get_world_size()))
+    gold = load_bench_golden("gf256")
+    mine = list(gold["ranks"][str(rank)])
+    if rank == corrupt:
+        mine[2] += 1
+    counters = torch.zeros(5, dtype=torch.int64)
+    for s in range(a.warmup + a.steps):
+        if s == a.warmup:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        if rank == die and s == a.warmup:
+            os._exit(3)
+        if rank == hang and s == a.warmup:
+            time.sleep(3600)
+        time.sleep(0.01)
+        counters.copy_(torch.tensor(mine, dtype=torch.int64))
+        if world > 1:
+            dist.all_reduce(counters)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    flags = torch.tensor([1, 0 if mine == gold["ranks"][str(rank)] else 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(flags)
+    ranks_checked, bad = int(flags[0]), int(flags[1])
+    check_ranks_against_golden(world, ranks_checked, bad)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (EMS_BENCH_FAKE_DECODE: no decode, not a measurement)", "value": 0.0, "unit": "frames/s",
+                          "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "fake", "config": {"workload": "fake decode", "frames_errframes_biterrs_undetected_sumiter": counters.tolist()},
+                          "counters_match_golden": bad == 0, "golden_ranks_checked": ranks_checked}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def check_ranks_against_golden(world, ranks_checked, bad):
+    """A multi-rank run of the committed workload must have EVERY rank's counters checked against the CPU oracle's
+    (tests/golden/bench_counters.json holds ranks 0..7) and equal: anything else ends the run non-zero on every rank (the
+    two numbers are all-reduced, so the ranks agree) instead of printing an aggregate nobody verified."""
+    if world > 1 and (ranks_checked != world or bad != 0):
+        sys.stderr.write("bench.py: %d of %d ranks were checked against the golden counters, %d differ: refusing to report\n" % (ranks_checked, world, bad))
+        raise SystemExit(2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,14 +612,20 @@ def main():
     ap.add_argument("--synthetic-zero-codeword", action="store_true",
                     help="skip the host encoder: all-zero codeword + numpy AWGN (faster set-up, same work)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a.gpus, sys.argv[1:])               # plain shell: this process only starts and watches the N ranks
 
-    import torch  # first: its bundled libamdhip64 must be the one the decoder library binds to
-    import __graft_entry__ as ge
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if os.environ.get("EMS_BENCH_FAKE_DECODE"):
+        return bench_fake(a, rank, world)
+    import torch  # first: its bundled libamdhip64 must be the one the decoder library binds to
+    import __graft_entry__ as ge
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the decoder library has no CPU fallback")
     torch.cuda.set_device(local)
@@ -514,7 +659,8 @@ def main():
         out = {
             "metric": "decoded frames/sec @ N=64800 GF(256) R=1/2, nm=20, 30 iters; 1/2/4/8 GPU" if a.workload == "gf256"
                       else "decoded frames/sec (%s)" % a.workload,
-            "value": main_res["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": main_res["value"], "unit": "frames/s", "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": main_res["data"],
             "config": {"workload": main_res["workload"],
