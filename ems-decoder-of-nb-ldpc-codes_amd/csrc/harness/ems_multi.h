@@ -75,10 +75,15 @@ static void *ems_multi_worker(void *argp)
         for (int i = 0; i < EMS_NCOUNTERS; i++) total.c[i] += v[i];
         st->count[dev] = err ? 0 : cnt_cur;
         pthread_barrier_wait(&st->bar);                   /* every device's results of the round are in place */
-        if (dev == 0 && !st->failed)
+        /* The failure flag is LATCHED here, between the two barriers: every write of round r happened before the first barrier and
+         * no thread can be past the second one, so all threads read the same value and take the same decision for round r.  (Read
+         * after the second barrier, a fast thread already failing in round r + 1 could make a slow one leave at r while the fast
+         * one waits for it in r + 1's all-reduce or barrier for ever.) */
+        const int failed_now = st->failed;
+        if (dev == 0 && !failed_now)
             st->truncated = ems_tally_round(&st->run, (const ems_frame_result *const *)st->res, st->count, ndev, st->max_err, ops->line, ops->ctx);
         pthread_barrier_wait(&st->bar);                   /* the tally has read them */
-        const int stop = st->failed || ems_global_stop(&total, st->n_frames, st->max_err);
+        const int stop = failed_now || ems_global_stop(&total, st->n_frames, st->max_err);
         if (stop) {
             if (cnt_next > 0 && !err) (void)ops->collect(ops->ctx, dev, slot ^ 1, cnt_next, NULL);   /* launched ahead of the stop: dropped */
             break;

@@ -144,6 +144,7 @@ typedef struct {
     float EbN, sigma_dev;
     unsigned long long gpu_seed;
     long long first_frame;
+    double allreduce_timeout_s;             /* watchdog of the per-round all-reduce (EMS_ALLREDUCE_TIMEOUT) */
     rccl_api nccl;
 } multi_ctx;
 
@@ -187,20 +188,46 @@ static int m_collect(void *c, int dev, int slot, int count, ems_frame_result *re
     return 0;
 }
 
-/* the path's one collective: ncclAllReduce(5 x int64, sum) on the device's own communicator and stream */
+/* the path's one collective: ncclAllReduce(5 x int64, sum) on the device's own communicator and stream.
+ * A device that cannot join the collective cannot be recovered in-process -- its peers are already inside it and would wait for ever --
+ * so every failure here, and an all-reduce that does not complete within EMS_ALLREDUCE_TIMEOUT seconds (default 120; the counters are
+ * 40 bytes), ends the whole process with a message naming the device instead of hanging the node. */
+static void m_allreduce_fatal(const dev_ctx *d, const char *what, const char *detail)
+{
+    fprintf(stderr, "\nems_sim: device %d: %s%s%s -- the per-round counter all-reduce cannot complete, stopping\n", d->hip_dev, what,
+            detail ? ": " : "", detail ? detail : "");
+    fflush(stderr);
+    _exit(EXIT_FAILURE);                  /* (not exit(): atexit handlers of RCCL / HIP could wait for the stuck collective) */
+}
+
 static int m_allreduce(void *c, int dev, long long v[EMS_NCOUNTERS])
 {
     multi_ctx *m = (multi_ctx *)c;
     dev_ctx *d = &m->d[dev];
     int nrc;
-    if (hipSetDevice(d->hip_dev) != hipSuccess ||
-        hipMemcpyAsync(d->d_cnt, v, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyHostToDevice, d->cstream) != hipSuccess) return -1;
-    if ((nrc = m->nccl.AllReduce(d->d_cnt, d->d_cnt + EMS_NCOUNTERS, EMS_NCOUNTERS, RCCL_INT64, RCCL_SUM, d->comm, d->cstream))) {
-        fprintf(stderr, "\nncclAllReduce on device %d: %s\n", d->hip_dev, m->nccl.GetErrorString(nrc));
-        return -1;
+    hipError_t he;
+    if ((he = hipSetDevice(d->hip_dev)) != hipSuccess) m_allreduce_fatal(d, "hipSetDevice", hipGetErrorString(he));
+    if ((he = hipMemcpyAsync(d->d_cnt, v, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyHostToDevice, d->cstream)) != hipSuccess)
+        m_allreduce_fatal(d, "staging copy", hipGetErrorString(he));
+    if ((nrc = m->nccl.AllReduce(d->d_cnt, d->d_cnt + EMS_NCOUNTERS, EMS_NCOUNTERS, RCCL_INT64, RCCL_SUM, d->comm, d->cstream)))
+        m_allreduce_fatal(d, "ncclAllReduce", m->nccl.GetErrorString(nrc));
+    if ((he = hipMemcpyAsync(v, d->d_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyDeviceToHost, d->cstream)) != hipSuccess)
+        m_allreduce_fatal(d, "result copy", hipGetErrorString(he));
+    /* watchdog: poll instead of hipStreamSynchronize, which has no deadline */
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; spins++) {
+        he = hipStreamQuery(d->cstream);
+        if (he == hipSuccess) break;
+        if (he != hipErrorNotReady) m_allreduce_fatal(d, "all-reduce stream", hipGetErrorString(he));
+        if (spins > 200) { const struct timespec nap = {0, 200000}; nanosleep(&nap, NULL); }     /* 0.2 ms once the fast path is over */
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > m->allreduce_timeout_s) {
+            char msg[96];
+            snprintf(msg, sizeof msg, "no completion after %.0f s (EMS_ALLREDUCE_TIMEOUT)", m->allreduce_timeout_s);
+            m_allreduce_fatal(d, "all-reduce watchdog", msg);
+        }
     }
-    if (hipMemcpyAsync(v, d->d_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyDeviceToHost, d->cstream) != hipSuccess ||
-        hipStreamSynchronize(d->cstream) != hipSuccess) return -1;
     return 0;
 }
 
@@ -212,6 +239,16 @@ static void m_line(const ems_counters *run, void *c)                   /* NB_LDP
            (double)run->c[EMS_CNT_ERR_FRAMES] / nb, (int)run->c[EMS_CNT_BIT_ERRORS],
            (double)run->c[EMS_CNT_BIT_ERRORS] / ((double)nb * m->K * m->logGF), (double)run->c[EMS_CNT_SUM_IT] / nb);
     fflush(stdout);
+}
+
+/* The all-reduce's stream gets the highest priority the device offers: its one small kernel is queued while the next round's decode
+ * workgroups (one per frame, persistent) hold every CU, and should take the first slot a finished frame frees rather than queue behind
+ * the decode's own backlog. */
+static hipError_t create_collective_stream(hipStream_t *s)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
 }
 
 /* EMS_DEVICES: the whole simulation loop on the listed devices; fills the reference's counters.  Returns 0 or exits. */
@@ -234,6 +271,8 @@ static int run_multi(const char *devlist, code_t *code, table_t *table, const em
     if (rccl_load(&m.nccl)) exit(EXIT_FAILURE);
     m.ndev = nd; m.code = code; m.table = table; m.EbN = EbN; m.gpu_source = gpu_source; m.gpu_seed = gpu_seed; m.first_frame = first_frame;
     m.K = code->K; m.logGF = code->logGF;
+    m.allreduce_timeout_s = getenv("EMS_ALLREDUCE_TIMEOUT") ? atof(getenv("EMS_ALLREDUCE_TIMEOUT")) : 120.0;
+    if (!(m.allreduce_timeout_s > 0.0)) m.allreduce_timeout_s = 120.0;
     m.threads_per_dev = threads / nd > 0 ? threads / nd : 1;
     m.sigma_dev = (float)sqrt(1.0 / (2.0 * (double)code->rate * pow(10.0, (double)EbN / 10.0)));   /* channel.c:51 */
     int batch = batch_env, rc;
@@ -259,7 +298,7 @@ static int run_multi(const char *devlist, code_t *code, table_t *table, const em
             d->noisy[s] = malloc(sizeof(float) * (size_t)batch * code->N * code->logGF);
         }
         d->iters = malloc(sizeof(int) * batch); d->synd = malloc(sizeof(int) * batch); d->nberr = malloc(sizeof(int) * batch);
-        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) != hipSuccess ||
+        if (hipSetDevice(devs[i]) != hipSuccess || create_collective_stream(&d->cstream) != hipSuccess ||
             hipMalloc((void **)&d->d_cnt, sizeof(long long) * 2 * EMS_NCOUNTERS) != hipSuccess) {
             fprintf(stderr, "device %d: cannot set up the all-reduce buffers\n", devs[i]);
             exit(EXIT_FAILURE);

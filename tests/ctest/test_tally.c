@@ -3,7 +3,10 @@
  * for any device count and batch size the ordered tally must be the single-device one -- same line after every frame, truncated
  * at exactly the frame that brings the erroneous frames to 40 (NB_LDPC.c:491-506) -- and every device must see the same
  * all-reduced counters.  Usage: test_tally <ndev> <batch> <n_frames> <error rate per 1000>; prints the trace; exit code 0 = equal
- * to the sequential tally. */
+ * to the sequential tally.
+ * Failure injection: three more arguments <device> <launch|collect> <k> make that device's k-th call (0-based) of that callback fail.
+ * The loop must then END on every thread -- nobody left in a barrier or in the all-reduce -- and ems_multi_run must return -1:
+ * exit code 4.  (A hang shows as the caller's timeout.) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,6 +21,8 @@ static unsigned mix(unsigned long long f)
     return (unsigned)(f >> 33);
 }
 static int g_rate = 30;
+static int g_fail_dev = -1, g_fail_kind = 0, g_fail_at = 0;     /* kind 1: launch, 2: collect */
+static int g_calls[64][3];
 static ems_frame_result fake_result(long long f)
 {
     const unsigned h = mix((unsigned long long)f);
@@ -44,6 +49,7 @@ typedef struct {
 static int f_launch(void *c, int dev, int slot, long long first, int count)
 {
     fake_ctx *x = (fake_ctx *)c;
+    if (dev == g_fail_dev && g_fail_kind == 1 && g_calls[dev][1]++ == g_fail_at) return -1;
     x->first[dev][slot] = first; x->count[dev][slot] = count;
     pthread_mutex_lock(&x->mu); x->launches++; pthread_mutex_unlock(&x->mu);
     return 0;
@@ -52,6 +58,7 @@ static int f_collect(void *c, int dev, int slot, int count, ems_frame_result *re
 {
     fake_ctx *x = (fake_ctx *)c;
     if (count != x->count[dev][slot]) return -1;
+    if (dev == g_fail_dev && g_fail_kind == 2 && res && g_calls[dev][2]++ == g_fail_at) return -1;
     if (!res) { pthread_mutex_lock(&x->mu); x->drains++; pthread_mutex_unlock(&x->mu); return 0; }
     for (int b = 0; b < count; b++) res[b] = fake_result(x->first[dev][slot] + b);
     return 0;
@@ -88,6 +95,11 @@ int main(int argc, char **argv)
     const long long n_frames = atoll(argv[3]);
     g_rate = atoi(argv[4]);
     if (ndev < 1 || ndev > 64) return 2;
+    if (argc >= 8) {
+        g_fail_dev = atoi(argv[5]);
+        g_fail_kind = strcmp(argv[6], "launch") == 0 ? 1 : 2;
+        g_fail_at = atoi(argv[7]);
+    }
     fake_ctx x;
     memset(&x, 0, sizeof x);
     x.ndev = ndev;
@@ -95,7 +107,11 @@ int main(int argc, char **argv)
     pthread_mutex_init(&x.mu, NULL);
     ems_multi_ops ops = {f_launch, f_collect, f_allreduce, f_line, &x};
     ems_counters fin;
-    if (ems_multi_run(&ops, ndev, n_frames, batch, 40, &fin)) { fprintf(stderr, "ems_multi_run failed\n"); return 3; }
+    if (ems_multi_run(&ops, ndev, n_frames, batch, 40, &fin)) {
+        fprintf(stderr, "ems_multi_run failed%s\n", g_fail_dev >= 0 ? " (as injected): every device thread came back" : "");
+        free(x.trace);
+        return g_fail_dev >= 0 ? 4 : 3;
+    }
 
     /* the single-device loop of the reference, frame after frame */
     fake_ctx y;

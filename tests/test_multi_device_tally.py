@@ -41,6 +41,17 @@ def test_fake_n_device_run_equals_sequential_tally(tally_exe, ndev, batch, frame
         assert int(last.group(2)) <= 40 and (int(last.group(2)) == 40 or int(last.group(3)) == frames)
 
 
+@pytest.mark.parametrize("ndev,batch,frames,dev,kind,at", [(4, 8, 4000, 2, "launch", 0), (4, 8, 4000, 0, "launch", 3), (8, 16, 100000, 5, "collect", 7),
+                                                            (3, 5, 2000, 2, "collect", 0), (2, 64, 5000, 1, "launch", 1), (8, 4, 100000, 7, "launch", 40)])
+def test_a_failing_device_ends_the_run_instead_of_hanging_it(tally_exe, ndev, batch, frames, dev, kind, at):
+    """One device's launch or collect fails in some round while the others are rounds ahead or behind: every thread must take the
+    same decision for that round (the failure flag is latched between the round's two barriers) and leave; a thread left waiting
+    in the all-reduce or a barrier would show as the timeout here."""
+    for _ in range(5):                                           # thread interleavings differ from run to run
+        out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), "3", str(dev), kind, str(at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert out.returncode == 4, (out.returncode, out.stderr.decode()[-2000:])
+
+
 def _trace(stdout):
     return [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
             re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", stdout.decode("latin-1"))]
