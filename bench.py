@@ -25,7 +25,8 @@ with HIP events on the stream it runs on; its name and workgroup shape are asked
 on a bounded sample of the same workload; N=1 only).  The line checks itself: `counters_match_golden`
 says whether the error counters of the timed run equal the CPU oracle's on the same frames
 (tests/golden/bench_counters.json).  At N=1 `config.other_workloads` carries short runs of BASELINE
-configs[1] (N96, batch 8192) and configs[2] (GF(16), batch 256), each with its own `roofline`.
+configs[1] (N96, batch 8192), configs[2] (GF(16), batch 256) and the v2 flavour of the headline code (batch 1536), each with its
+own `roofline` and its own check against an oracle golden.
 """
 import argparse
 import importlib
@@ -48,6 +49,40 @@ WORKLOADS = {
     # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (synthetic_likelihood below, sigma 0.95)
     "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1536),
 }
+KERNEL_SOURCES = ["ems_kernels.hip", "ems_plan.h", "kernels/ems_lanes.inc", "kernels/ems_es.inc", "kernels/ems_es_q16.inc", "kernels/ems_cn.inc",
+                  "kernels/ems_decode.inc", "kernels/ems_v2.inc"]
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources the decode kernels are compiled from.  scripts/pmc_summary.py stores it in
+    profiles/traffic_*.json next to the PMC measurement; `roofline.traffic` is only printed while the two agree -- a committed
+    measurement of a kernel that has since changed is refused instead of going stale silently."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "ems-decoder-of-nb-ldpc-codes_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(name, kernel, B):
+    """(bytes per launch of B frames, provenance) from profiles/traffic_<name>.json, or (None, why not)."""
+    tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+    if not os.path.exists(tr):
+        return None, None
+    try:
+        tj = json.load(open(tr))
+        if tj["kernel"].split("::")[-1].split("(")[0] != kernel:
+            return None, "profiles/traffic_%s.json measures another kernel (%s): not printed" % (name, tj["kernel"].split("::")[-1].split("(")[0])
+        if tj.get("kernel_source_sha16") != kernel_source_hash():
+            return None, "profiles/traffic_%s.json was measured on other kernel sources (sha16 %s, now %s): refused, re-run scripts/pmc_passes.sh" % (
+                name, tj.get("kernel_source_sha16"), kernel_source_hash())
+        return int(tj["hbm_bytes_per_frame"] * B), ("profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (same kernel sources, sha16 %s) at %d "
+                                                    "frames per launch, scaled per frame (committed measurement, not this run)" % (name, tj["kernel_source_sha16"], tj["frames_per_launch"]))
+    except Exception as e:                                      # a broken file is not worth a failed bench
+        return None, "profiles/traffic_%s.json unreadable: %s" % (name, e)
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -90,30 +125,34 @@ def synthetic_likelihood(N, q, logq, idx2bin, sigma, seed):
     return np.ascontiguousarray(np.take_along_axis(llr, order, axis=1), np.float32), np.ascontiguousarray(order.astype(np.int32))
 
 
-def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
-    """The v2 flavour's line: same contract, the step is init-from-staged-likelihoods + k_decode_v2 + results.
-    (oracle/ is imported only by the cpu_baseline leg.)"""
-    mat, nm, nop, off, itmax, _e, B0 = WORKLOADS["gf256_v2"]
-    B = a.batch or B0
+def run_v2_workload(a, pkg, ge, torch, dist, rank, world, local, B, steps, warmup):
+    """Timed fixed-work steps of the v2 flavour on this rank's GPU (init-from-staged-likelihoods + k_decode_v2 + results); returns what
+    rank 0 prints.  Self-check: syndrome, iteration count and CRC-32 of the decisions of the 8 distinct frames against the v2 oracle's
+    (tests/golden/bench_counters.json["gf256_v2"], tests/golden/make_bench_golden.py) -- oracle/ itself is not touched here."""
+    import zlib
+    mat, nm, nop, off, itmax, _e, _B0 = WORKLOADS["gf256_v2"]
     matrix = os.path.join(ge.MATRICES, mat)
     code = pkg.Code(matrix)
     idx2bin, _b2i = pkg.gf_tables(code.GF)
     sigma = 0.95
+    ND = 8
     t_setup = time.time()
-    base = [synthetic_likelihood(code.N, code.GF, code.logGF, idx2bin, sigma, 1000 * rank + s) for s in range(8)]
-    like = np.stack([base[i % 8][0] for i in range(B)])
-    idx = np.stack([base[i % 8][1] for i in range(B)])
+    base = [synthetic_likelihood(code.N, code.GF, code.logGF, idx2bin, sigma, 1000 * rank + s) for s in range(ND)]
+    like = np.stack([base[i % ND][0] for i in range(B)])
+    idx = np.stack([base[i % ND][1] for i in range(B)])
     t_setup = time.time() - t_setup
     dec = pkg.Decoder(code, nm, nop, off, itmax, max_batch=B, device=local, early_exit=False)
     dec.v2_load_likelihood(like, idx)                  # staged in HBM before the timed region
     dec.synchronize()
     counters = torch.zeros(3, dtype=torch.int64, device="cuda")
+    last = [None, None]
 
     def step():
         dec.v2_reinit(B)
         dec.v2_decode(B)
         it = np.zeros(B, np.int32); sy = np.zeros(B, np.int32)
         pkg._check(pkg.lib().ems_get_results(dec.h, B, None, pkg._ptr(it), pkg._ptr(sy)))
+        last[0], last[1] = it, sy
         counters.copy_(torch.tensor([B, int((sy != 0).sum()), int(it.sum())], dtype=torch.int64))
         if dist is not None:
             dist.all_reduce(counters)
@@ -124,12 +163,12 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
         if dist is not None:
             dist.barrier(); torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
     kms, lms = [], []
-    for _ in range(a.steps):
+    for _ in range(steps):
         k, l = step(); kms.append(k); lms.append(l)
     fence()
     dt = time.perf_counter() - t0
@@ -137,36 +176,52 @@ def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- self-check against the v2 oracle's golden (rank 0's seeds; every copy of a distinct frame must agree) ----
+    gold = load_bench_golden("gf256_v2")
+    match = None
+    if gold is not None and rank == 0 and B >= ND and [gold["nm"], gold["NbOper"], gold["NbIterMax"], gold["distinct_frames"]] == [nm, nop, itmax, ND]:
+        dcd = np.zeros((ND, code.N), np.int32)
+        pkg._check(pkg.lib().ems_get_results(dec.h, ND, pkg._ptr(dcd), None, None))
+        it, sy = last
+        match = True
+        for s_, (gs, gi, gc) in enumerate(gold["synd_iters_crc32decisions"]):
+            match = match and bool((sy[s_::ND] == gs).all()) and bool((it[s_::ND] == gi).all()) and zlib.crc32(dcd[s_].astype(np.uint8).tobytes()) == gc
+    alg = algorithmic_bytes_per_frame_decode_v2(code.N, code.E, code.GF, nm, itmax + 1) * B
+    kavg = float(np.mean(kms)) * 1e-3
+    res = {"value": round(world * B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+           "data": "synthetic: seeded max-is-best likelihoods of an all-zero BPSK/AWGN codeword, sigma %.2f, %d distinct frames tiled" % (sigma, ND),
+           "workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
+           "batch_per_gpu": B, "counters": counters.cpu().tolist(), "counters_match_golden": match,
+           "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d waves per workgroup, %d frames per launch on %d CUs)" % (dec.last_kernel, dec.last_workgroup_waves, B, dec.n_cu),
+                        "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
+           "host_setup_s": round(t_setup, 1), "matrix": matrix, "params": (nm, nop, off, itmax, sigma)}
+    res["roofline"]["traffic"], res["roofline"]["traffic_source"] = committed_traffic("gf256_v2", dec.last_kernel, B)
+    dec.close()
+    return res
+
+
+def bench_v2(a, pkg, ge, torch, dist, rank, world, local):
+    """`--workload gf256_v2`: the v2 flavour's own line, same contract.  (oracle/ is imported only by the cpu_baseline leg.)"""
+    B = a.batch or WORKLOADS["gf256_v2"][6]
+    r = run_v2_workload(a, pkg, ge, torch, dist, rank, world, local, B, a.steps, a.warmup)
     if rank == 0:
-        alg = algorithmic_bytes_per_frame_decode_v2(code.N, code.E, code.GF, nm, itmax + 1) * B
-        kavg = float(np.mean(kms)) * 1e-3
+        nm, nop, off, itmax, sigma = r["params"]
         out = {"metric": "decoded frames/sec, v2 flavour (truncated messages both ways) @ N=64800 GF(256) R=1/2, nm=20, 29 iterations",
-               "value": round(world * B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic: seeded max-is-best likelihoods of an all-zero BPSK/AWGN codeword, sigma %.2f, 8 distinct frames tiled" % sigma,
-               "config": {"workload": "%s v2 flavour nm=%d NbIterMax=%d (%d iterations) offset=%.1f NbOper=%d, fixed work (early exit off)" % (mat, nm, itmax, itmax + 1, off, nop),
-                          "batch_per_gpu": B, "sharding": "independent frames", "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
-                          "frames_nonzero_syndromes_sumiter": counters.cpu().tolist()},
-               "roofline": {"bound": "hbm", "kernel": "%s (persistent, 1 workgroup per frame, %d waves per workgroup, %d frames per launch on %d CUs)" % (dec.last_kernel, dec.last_workgroup_waves, B, dec.n_cu),
-                            "achieved": round(alg / kavg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / kavg / 1e9 / HBM_PEAK_GBS, 5),
-                            "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg * 1e3, 3), "init_avg_ms": round(float(np.mean(lms)), 3)},
-               "host_setup_s": round(t_setup, 1)}
-        tr = os.path.join(ROOT, "profiles", "traffic_gf256_v2.json")
-        out["roofline"]["traffic_source"] = None
-        if os.path.exists(tr):
-            try:
-                tj = json.load(open(tr))
-                if tj["kernel"].split("::")[-1].split("(")[0] == dec.last_kernel:
-                    out["roofline"]["traffic"] = int(tj["hbm_bytes_per_frame"] * B)
-                    out["roofline"]["traffic_source"] = ("profiles/traffic_gf256_v2.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at %d "
-                                                         "frames per launch, scaled per frame (committed measurement, not this run)" % tj["frames_per_launch"])
-            except Exception:
-                pass
+               "value": r["value"], "unit": "frames/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+               "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": r["data"],
+               "config": {"workload": r["workload"], "batch_per_gpu": B, "sharding": "independent frames",
+                          "collective": "all-reduce of 3 int64 counters per step" if world > 1 else "none",
+                          "frames_nonzero_syndromes_sumiter": r["counters"]},
+               "counters_match_golden": r["counters_match_golden"],
+               "roofline": r["roofline"], "host_setup_s": r["host_setup_s"]}
         if world == 1 and not a.no_cpu_baseline:
             import importlib as il
             ge.load_oracle()
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            out["cpu_baseline"] = cpu_baseline_v2(il.import_module("orc_v2"), matrix, nm, nop, off, itmax, sigma,
+            out["cpu_baseline"] = cpu_baseline_v2(il.import_module("orc_v2"), r["matrix"], nm, nop, off, itmax, sigma,
                                                    max(1, min(os.cpu_count() or 1, 16)))
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -450,19 +505,36 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
         "host_setup_s": round(t_setup, 1), "oper": oper, "b256": b256,
         "matrix": matrix, "params": (nm, nop, off, itmax, ebn),
     }
-    # HBM bytes per launch from the PMC passes kept under profiles/ (scripts/pmc_passes.sh on an earlier box, same kernel):
-    # a committed measurement scaled to this batch, NOT a measurement of this run -- labelled as such
-    tr = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-    if os.path.exists(tr):
-        try:
-            tj = json.load(open(tr))
-            if tj["kernel"].split("::")[-1].split("(")[0] == kernel:
-                res["roofline"]["traffic"] = int(tj["hbm_bytes_per_frame"] * B)
-                res["roofline"]["traffic_source"] = ("profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at %d "
-                                                     "frames per launch, scaled per frame (committed measurement, not this run)" % (workload, tj["frames_per_launch"]))
-        except Exception:
-            pass
+    # HBM bytes per launch from the PMC passes kept under profiles/ (scripts/pmc_passes.sh on an earlier box, same kernel AND same kernel
+    # sources): a committed measurement scaled to this batch, NOT a measurement of this run -- labelled as such, refused when stale
+    res["roofline"]["traffic"], res["roofline"]["traffic_source"] = committed_traffic(workload, kernel, B)
+    if workload == "n96":
+        relabel_cache_resident(res["roofline"], code.M * sweeps * B, kavg, n_cu)
     return res
+
+
+VALU_CLOCK_GHZ = 2.4        # MI355X peak engine clock (MI355X_MICROARCH.md); a wave64 VALU instruction occupies its SIMD for 4 cycles
+
+
+def relabel_cache_resident(rf, visits_per_launch, launch_s, n_cu):
+    """N96 (BASELINE configs[1]): the whole state of a frame (APP 24 KiB + records) lives in the caches -- measured HBM traffic is BELOW
+    the algorithmic bytes (profiles/traffic_n96.json) -- so HBM does not bound the kernel; SURVEY.md 8(d) says as much.  What bounds it is
+    the VALU issue rate: `achieved` = wave-level VALU instructions per second = SQ_INSTS_VALU per check-node visit (committed SQ passes
+    of the same kernel sources) x visits per launch / the launch time measured by THIS run; `peak` = CUs x 4 SIMDs x clock / 4 cycles per
+    wave64 instruction.  The HBM figures stay beside it under `hbm`."""
+    rf["hbm"] = {k: rf[k] for k in ("achieved", "peak", "unit", "frac")}
+    per_visit, why = None, "no SQ passes of the current kernel sources under profiles/ (re-run scripts/pmc_passes.sh)"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_n96.json")))
+        if tj.get("kernel_source_sha16") == kernel_source_hash():
+            per_visit = float(tj["sq_per_visit"]["SQ_INSTS_VALU"])
+            why = "profiles/traffic_n96.json: SQ_INSTS_VALU per visit = %.1f (committed rocprofv3 --pmc pass, same kernel sources) x %d visits / this run's launch time" % (per_visit, visits_per_launch)
+    except Exception:
+        pass
+    peak = n_cu * 4 * VALU_CLOCK_GHZ / 4.0                     # G wave-instructions / s
+    ach = None if per_visit is None else per_visit * visits_per_launch / launch_s / 1e9
+    rf.update({"bound": "valu", "achieved": None if ach is None else round(ach, 2), "peak": round(peak, 2), "unit": "G wave-instr/s (VALU)",
+               "frac": None if ach is None else round(ach / peak, 5), "valu_source": why})
 
 
 def _free_port():
@@ -654,6 +726,10 @@ def main():
             others[w] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": 5, "warmup": 2, "workload": r["workload"],
                          "batch": r["batch_per_gpu"], "frames_errframes_biterrs_undetected_sumiter": r["counters"],
                          "counters_match_golden": r["counters_match_golden"], "roofline": r["roofline"]}
+        r = run_v2_workload(a, pkg, ge, torch, None, rank, 1, local, WORKLOADS["gf256_v2"][6], 3, 1)
+        others["gf256_v2"] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1, "workload": r["workload"],
+                              "batch": r["batch_per_gpu"], "frames_nonzero_syndromes_sumiter": r["counters"],
+                              "counters_match_golden": r["counters_match_golden"], "roofline": r["roofline"], "data": r["data"]}
     if rank == 0:
         nm, nop, off, itmax, ebn = main_res["params"]
         out = {

@@ -1,6 +1,8 @@
 """Developer probe: summarise the rocprofv3 --pmc passes of scripts/pmc_passes.sh for the decode kernel.
 usage: python scripts/pmc_summary.py gpurun_out/<tag> <frames per launch> [visits per frame] [--json out.json]"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 tag, B = sys.argv[1], int(sys.argv[2])
 visits = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 4050 * 29
 out = {}
@@ -13,7 +15,7 @@ for p in ("fetch", "write", "sq1", "sq2"):
             kname = r["Kernel_Name"]
             out.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in out.items()}
-res = {"kernel": kname, "frames_per_launch": B}
+res = {"kernel": kname, "frames_per_launch": B, "kernel_source_sha16": bench.kernel_source_hash()}
 if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     rd, wr = avg["FETCH_SIZE"] * 1024 * 2, avg["WRITE_SIZE"] * 1024
     res.update({"FETCH_SIZE_KB_avg": avg["FETCH_SIZE"], "WRITE_SIZE_KB_avg": avg["WRITE_SIZE"],

@@ -12,6 +12,12 @@ sum of iterations; NB_LDPC.c:474-497) that bench.py compares its timed run with 
 
     python tests/golden/make_bench_golden.py [gf256] [gf16] [n96]     (run from the repo root; gf256 takes ~15 min on 8 cores)
     python tests/golden/make_bench_golden.py --ranks 1 2 ... 7          (the headline counters of ranks 1.. of a multi-GPU bench)
+    python tests/golden/make_bench_golden.py gf256_v2                   (the v2 flavour's step: its 8 distinct frames, rank 0)
+
+gf256_v2 (bench.py's `other_workloads.gf256_v2`): the v2 oracle (oracle/ems_v2_oracle.c, pinned against the real v2 translation
+unit by tests/test_v2_oracle_vs_reference.py) on the 8 seeded synthetic likelihood frames the bench tiles over its batch
+(seeds 0..7 = rank 0), NbIterMax 28 = 29 iterations, fixed work: per frame the syndrome value, the iteration count and the CRC-32
+of the hard decisions (as u8).
 """
 import json
 import os
@@ -68,6 +74,27 @@ def generate(name, threads, rank=0):
     return rec, counters
 
 
+V2 = ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, 0.95, 8)          # bench.py's WORKLOADS["gf256_v2"] + its sigma and distinct frames
+
+
+def generate_v2(threads):
+    import orc_v2
+    mat, nm, nop, off, itmax, sigma, F = V2
+    o = orc_v2.V2Oracle(os.path.join(ROOT, "tests", "golden", "matrices", mat))
+
+    def one(s):
+        like, idx = orc_v2.synthetic_likelihood(o.N, o.q, o.logq, o.o.idx2bin, sigma, s)
+        r = o.decode(like, idx, nm, nop, off, itmax, early_exit=False)
+        return [int(r["synd"]), int(r["iters"]), int(orc.crc32(r["decide"].astype(np.uint8)))]
+
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        rec = list(ex.map(one, range(F)))
+    print("gf256_v2: %d frames in %.0f s: %s" % (F, time.time() - t0, rec), flush=True)
+    return {"matrix": mat, "nm": nm, "NbOper": nop, "offset": off, "NbIterMax": itmax, "sigma": sigma, "distinct_frames": F, "seeds": list(range(F)),
+            "synd_iters_crc32decisions": rec}
+
+
 def add_ranks(ranks, threads):
     """bench_counters.json["gf256"]["ranks"][r]: the counters of rank r's batch of a `bench.py --gpus N` run (r >= 1; counters only)."""
     cj = os.path.join(ROOT, "tests", "golden", "bench_counters.json")
@@ -94,6 +121,10 @@ if __name__ == "__main__":
     arrays = dict(np.load(npz)) if os.path.exists(npz) else {}
     counters = json.load(open(cj)) if os.path.exists(cj) else {}
     for name in which:
+        if name == "gf256_v2":
+            counters[name] = generate_v2(threads)
+            json.dump(counters, open(cj, "w"), indent=1)
+            continue
         rec, cnt = generate(name, threads)
         mat, nm, nop, off, itmax, ebn, F = WORKLOADS[name]
         arrays[name] = rec.astype(np.int64)         # columns: bit errors, syndrome, iterations, CRC-32(decisions as u8), CRC-32(APP)
