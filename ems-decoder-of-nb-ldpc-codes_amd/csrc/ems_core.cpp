@@ -85,7 +85,7 @@ struct CnSchedule {
 
 int build_cn_schedule(int dc, CnSchedule &s)
 {
-    if (dc < 2 || dc > 16) return fail(EMS_EUNSUPPORTED, "check-node degree %d not supported", dc);
+    if (dc < 2 || dc > EMS_MAX_DC) return fail(EMS_EUNSUPPORTED, "check-node degree %d not supported (2..%d)", dc, EMS_MAX_DC);
     auto in = [&](int i) { return i; };
     auto Pl = [&](int k) { return k == 0 ? in(0) : dc + (k - 1); };
     auto Sl = [&](int k) { return k == dc - 1 ? in(dc - 1) : dc + (dc - 2) + (k - 1); };
@@ -111,7 +111,7 @@ int build_cn_schedule(int dc, CnSchedule &s)
             }
     }
     memset(s.out_list, 0, sizeof s.out_list);
-    for (int t = 0; t < dc; ++t)
+    for (int t = 0; t < dc && t < 16; ++t)                  // (degrees above 16: k_decode_wide / k_cn_unit compute the list from the degree)
         s.out_list[t] = (int8_t)(t == 0 ? Sl(1) : (t == dc - 1 ? Pl(dc - 2) : Ml(t - 1)));
     return EMS_OK;
 }
@@ -181,6 +181,7 @@ struct ems_handle {
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
+    bool wide = false;                   // largest check degree above 16: k_decode_wide
     bool regular = true;                 // every check node has degree dc; else dc = the largest degree and the tables below are used
     std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
     DevBuf<int> d_row_ptr, d_t_dc, d_t_e0;
@@ -355,22 +356,25 @@ int refresh_plan(ems_handle *h)
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
     P.rec_bytes = ems_rec_bytes(h->nm_alloc);
-    P.wave_lds_bytes = (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
+    P.wide = h->wide ? 1 : 0;
+    P.wave_lds_bytes = h->wide ? (int)ems_wide_wave_lds_bytes(h->q, h->dc, p.nm) : (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
     int widest = 1;
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-    const int wcap = ems_max_waves_for(h->dc, h->q);
+    const int wcap = h->wide ? 4 : ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
     if (h->tune.waves > 0) waves = std::max(1, std::min(wcap, h->tune.waves));                  // ems_set_tuning
     const size_t lds_cap = 160 * 1024;
     while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
-    if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) return fail(EMS_EUNSUPPORTED, "LDS budget exceeded");
+    if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap)
+        return fail(EMS_EUNSUPPORTED, "check degree %d with nm = %d over GF(%d): the %zu bytes of message lists of one check node do not fit the 160 KiB of LDS", h->dc,
+                    p.nm, h->q, ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves));
     P.waves_per_wg = waves;
     P.occ4 = 0;
     P.stamps = h->d_stamps.p;
     P.fail = h->d_fail.p;
     P.cn_ptr = h->d_row_ptr.p;
-    P.t_dc = h->regular ? nullptr : h->d_t_dc.p;                // non-null = irregular code: generic one-visit kernel, per-visit degree
-    P.t_e0 = h->regular ? nullptr : h->d_t_e0.p;
+    P.t_dc = (h->regular && !h->wide) ? nullptr : h->d_t_dc.p;  // non-null = irregular code (generic one-visit kernel, per-visit degree) or k_decode_wide
+    P.t_e0 = (h->regular && !h->wide) ? nullptr : h->d_t_e0.p;
     return EMS_OK;
 }
 
@@ -647,10 +651,11 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->row_ptr[m + 1] = (int)E;
     }
     if (E != c->nbBranch) return bail(fail(EMS_EINVAL, "nbBranch does not match the row degrees"));
-    if (!ems_lpe_for(h->dc))
-        return bail(fail(EMS_EUNSUPPORTED, "check degree %d: the kernels give every edge of a check node a row of at least 4 of the wavefront's 64 lanes, "
-                                           "i.e. at most 16 edges (the reference's matrices stop at 12)", h->dc));
-    if (h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
+    // Up to 16 edges a check node's edges each own a row of the wavefront's lanes; above that (the reference's Ahmed_64800_R910_GF256 has
+    // dc = 20, and it caps the degree nowhere: init.c:320, bubble_decoder.c:166-227) k_decode_wide walks them in passes.
+    if (h->dc > EMS_MAX_DC) return bail(fail(EMS_EUNSUPPORTED, "check degree %d: degrees up to %d are built", h->dc, EMS_MAX_DC));
+    h->wide = h->dc > 16;
+    if (!h->wide && h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 
     // Edge tables + level schedule (see level_schedule above).
@@ -794,7 +799,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     P.occ4 = 0;
     P.dual = 0;
     P.twin = 0;
-    if (!h->regular) return;                                    // irregular check degrees: the generic one-visit kernel in the plan's shape
+    if (!h->regular || h->wide) return;                         // irregular check degrees / degrees above 16: the generic kernels in the plan's shape
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
     };

@@ -10,6 +10,8 @@ int ems_lpe_for(int dc);                                     // lanes per edge r
 int ems_max_waves_for(int dc, int q);                      // waves per workgroup k_decode is built for
 size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists);
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
+int ems_wide_lpe(int q);                                     // lanes per edge row of k_decode_wide (check degree above 16)
+size_t ems_wide_wave_lds_bytes(int q, int dc, int nm);
 bool ems_has_occ4_kernel(const EmsPlan &P);
 bool ems_has_dual_kernel(const EmsPlan &P);                  // two check-node visits per wave (GF(256) dc 4 nm 20; GF(16) dc 8 nm 8)
 bool ems_has_v2_dual_kernel(const EmsPlan &P);               // the v2 flavour's two-visit kernel (GF(256) dc 4 nm 20)

@@ -6,7 +6,7 @@
 //     topological order of the layered schedule's dependency DAG (NB_LDPC.c:320 order is preserved per variable node)
 //     and a visit waits only for the visits it depends on (done flags in LDS); sweeps are separated by __syncthreads();
 //   * k_decode: one WAVEFRONT per check-node visit; the 64 lanes are split into dc "edge rows" of LPE lanes (LPE = 16 for
-//     dc <= 4, 8 for dc <= 8, 4 beyond); k_decode_dual (the throughput form, BASELINE message sizes): TWO visits per
+//     dc <= 4, 8 for dc <= 8, 4 up to 16; above 16 k_decode_wide walks the edges in passes of 64 / LPE rows); k_decode_dual (the throughput form, BASELINE message sizes): TWO visits per
 //     wavefront, rows of 8 lanes (dc = 4) or 4 lanes (dc = 8).  Each row owns one edge: its q-wide APP row is read from
 //     HBM with 16-byte coalesced loads and stays in registers (q/LPE values per lane) from the variable-node extract
 //     (NB_LDPC.c:329-337) to the posterior update (NB_LDPC.c:444-450);
@@ -134,6 +134,18 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const Em
     hipLaunchKernelGGL((k_decode_twin<Q, NM, DC>), dim3((B + 1) / 2), dim3(64), lds, st, P, B);
     return hipGetLastError();
 }
+// check degree above 16 (k_decode_wide)
+int ems_wide_lpe(int q) { return wide_lpe(q); }
+size_t ems_wide_wave_lds_bytes(int q, int dc, int nm) { return (size_t)wide_wave_bytes(q, dc, nm); }
+template <int Q, int LPE> static hipError_t launch_decode_wide_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    g_kname = kname_fmt("k_decode_wide<%d, %d>", Q, LPE);
+    const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_wide<Q, LPE>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_wide<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
 // kernels that also exist in the 16-waves-per-CU build
 bool ems_has_occ4_kernel(const EmsPlan &P) { return spec_ok(P) && P.q == 256 && P.dc == 4 && P.nm == 20; }
 
@@ -147,6 +159,14 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st, const char
 }
 static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
 {
+    if (P.wide) {
+        if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > 4 || P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm))
+            return hipErrorInvalidValue;
+        if (P.q == 256) return launch_decode_wide_t<256, 8>(P, B, st);
+        if (P.q == 64) return launch_decode_wide_t<64, 4>(P, B, st);
+        if (P.q == 16) return launch_decode_wide_t<16, 4>(P, B, st);
+        return hipErrorInvalidValue;
+    }
     const int lpe = ems_lpe_for(P.dc);
     // kernels specialised for the BASELINE configurations (dc, nm compile-time; need nm+3 <= nbOper <= 64)
     const bool spec = spec_ok(P) && P.t_dc == nullptr;       // (irregular check degrees: the generic kernels with per-visit degrees)
@@ -231,10 +251,12 @@ hipError_t ems_launch_cn_unit(const EmsPlan &P, const int *coef, const float *vt
                               hipStream_t st)
 {
     const size_t lds = (((size_t)P.n_lists * list_stride(P.nm) * 8 + 15) & ~(size_t)15) + (((size_t)P.n_lists * 4 + 15) & ~(size_t)15);
-    if (P.q == 256) hipLaunchKernelGGL((k_cn_unit<256>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
-    else if (P.q == 64) hipLaunchKernelGGL((k_cn_unit<64>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
-    else if (P.q == 16) hipLaunchKernelGGL((k_cn_unit<16>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov);
+    hipError_t e = hipSuccess;                                  // (large degrees: the lists of one check node can pass the default 64 KiB)
+    if (P.q == 256) { if ((e = set_max_lds(k_cn_unit<256>, lds)) == hipSuccess) hipLaunchKernelGGL((k_cn_unit<256>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov); }
+    else if (P.q == 64) { if ((e = set_max_lds(k_cn_unit<64>, lds)) == hipSuccess) hipLaunchKernelGGL((k_cn_unit<64>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov); }
+    else if (P.q == 16) { if ((e = set_max_lds(k_cn_unit<16>, lds)) == hipSuccess) hipLaunchKernelGGL((k_cn_unit<16>), dim3(1), dim3(64), lds, st, P, coef, vtoc_llr, vtoc_gf, ctov); }
     else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -17,7 +17,8 @@ struct EmsEntry {
 #define EMS_S_BOUND 0x200u
 #define EMS_MAX_NM 40      // messages longer than this are not built (reference usage: 8..30); above EMS_FAST_NM the literal forms run
 #define EMS_FAST_NM 32     // the merge form of the elementary step records a list position in 5 bits, the selection keeps 32 survivors
-#define EMS_MAX_STEPS 14   // dc-2 forward/backward steps (dc <= 16)
+#define EMS_MAX_STEPS 14   // dc-2 forward/backward steps of the kernels that keep a stage table (dc <= 16)
+#define EMS_MAX_DC 64      // check degrees 17..64 run k_decode_wide (edges in passes, tasks computed from the degree); LDS permitting
 
 // Compact check-to-variable record kept in HBM per (frame, edge).  The reference stores a dense
 // q-wide float row per edge (init.c:323-328) although a C->V message is nm (LLR, symbol) pairs plus
@@ -73,6 +74,7 @@ struct EmsPlan {
     // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)
+    int wide;               // launch k_decode_wide (check degree above 16: the edges of a visit in passes; t_dc / t_e0 always set)
     int twin;               // launch k_decode_twin: one wave per PAIR OF FRAMES, check nodes in reference order (tiny codes)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)
     const int *p_vn;        // [n_pairs*2dc] variable nodes, row = member * dc + edge

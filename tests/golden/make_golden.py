@@ -71,6 +71,17 @@ def kat_traces():
         # messages longer than the 32 entries the fast forms hold (the reference caps nm nowhere; start.sh runs 30)
         "N40": ("ubs", "N96_K48_GF64", 150, 10, 2.0, 40, 0.3, 60),
         "N36": ("ubs", "LOCAL/Irr345_N60_M24_GF256", 60, 8, 3.0, 36, 0.3, 72),
+        # check degrees above 16 (the reference sizes its scratch by rowDegree[0] with no cap, init.c:320; bubble_decoder.c:166-227 loops over
+        # any dc): the rate-9/10 GF(256) matrix has dc = 20; dc = 10 is the rate-4/5 one (the dc 9..16 path was tested at dc = 12 only)
+        "D20": ("ubs", "Ahmed_64800_R910_GF256", 3, 30, 3.7, 20, 0.3, 40),
+        "D20b": ("ubs", "Ahmed_64800_R910_GF256", 3, 30, 4.0, 20, 0.3, 40),
+        "D10": ("ubs", "Ahmed_64800_R45_GF256", 3, 30, 2.8, 20, 0.3, 40),
+        "D10b": ("ubs", "Ahmed_64800_R45_GF256", 3, 30, 3.0, 20, 0.3, 40),
+        # small irregular codes with every check degree above 16 (make_wide_matrix.py; row 0 carries the largest): 17..24 over GF(64) / GF(256),
+        # 25..40 over GF(16)
+        "W1": ("ubs", "LOCAL/Wide_N80_M8_GF64", 200, 10, 4.5, 16, 0.3, 32),
+        "W2": ("ubs", "LOCAL/Wide_N80_M8_GF256", 150, 12, 4.5, 20, 0.3, 40),
+        "W3": ("ubs", "LOCAL/Wide_N120_M6_GF16", 150, 10, 5.0, 8, 0.3, 16),
     }
     dst = os.path.join(HERE, "kat_traces.json")
     out = json.load(open(dst)) if os.path.exists(dst) and os.environ.get("KAT_KEEP", "1") == "1" else {}

@@ -40,7 +40,7 @@ def test_check_node_golden(pkg):
 
 
 @pytest.mark.parametrize("q,nm,dc", [(64, 16, 4), (256, 20, 4), (16, 8, 8), (64, 12, 3), (64, 12, 6), (256, 10, 5), (256, 32, 4),
-                                     (64, 8, 2), (16, 5, 4)])
+                                     (64, 8, 2), (16, 5, 4), (256, 20, 20), (64, 16, 17), (16, 8, 33), (256, 12, 10)])
 def test_check_node_random_vs_oracle(pkg, orc, q, nm, dc):
     o = FieldOracle(orc, q)
     rs = np.random.RandomState(q + nm + dc)
@@ -225,6 +225,32 @@ def test_decode_gf256_dc8_vs_oracle(pkg, orc):
 def test_decode_gf256_dc12_vs_oracle(pkg, orc):
     """Rate 5/6 GF(256) code of the reference's matrices/ (dc = 12): rows of 4 lanes with 64 symbols per lane."""
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R56_GF256", 20, 40, 0.3, 6, 4.6, 1, state=True)
+
+
+def test_decode_check_degrees_above_16_vs_oracle(pkg, orc):
+    """Check degrees above 16 (k_decode_wide: the edges of a visit in passes of 64 / LPE rows, Mvc recomputed for the output pass): the
+    reference caps the degree nowhere (init.c:320, bubble_decoder.c:166-227).  Small irregular codes with degrees 17..24 over GF(64) /
+    GF(256) and 25..40 over GF(16) (tests/golden/make_wide_matrix.py; kat_traces.json W1..W3 are the REAL executable's traces on them):
+    whole-frame state -- decisions, iterations, syndrome, bit errors, APP, every C->V row -- against the oracle, fast and literal forms."""
+    _decode_vs_oracle(pkg, orc, "Wide_N80_M8_GF64", 16, 32, 0.3, 10, 4.5, 24)
+    _decode_vs_oracle(pkg, orc, "Wide_N80_M8_GF64", 12, 15, 1.0, 6, 3.0, 8, early_exit=False)      # NbOper < nm + 3
+    _decode_vs_oracle(pkg, orc, "Wide_N80_M8_GF256", 20, 40, 0.3, 12, 4.5, 16)
+    _decode_vs_oracle(pkg, orc, "Wide_N80_M8_GF256", 36, 72, 0.3, 6, 4.0, 6)                       # literal forms (nm > 32)
+    _decode_vs_oracle(pkg, orc, "Wide_N120_M6_GF16", 8, 16, 0.3, 10, 5.0, 16)                      # three passes, first-occurrence form
+    _decode_vs_oracle(pkg, orc, "Wide_N120_M6_GF16", 12, 24, 0.5, 8, 4.0, 8, early_exit=False)
+
+
+def test_decode_gf256_dc20_vs_oracle(pkg, orc):
+    """The reference's rate-9/10 GF(256) matrix (Ahmed_64800_R910_GF256, dc = 20; kat_traces.json D20 / D20b from the real executable):
+    a frame that converges and one that does not, whole state."""
+    it = _decode_vs_oracle(pkg, orc, "Ahmed_64800_R910_GF256", 20, 40, 0.3, 30, 4.0, 2, state=True)
+    assert list(it) == [6, 6]                                                                      # D20b: 6.00, 6.00, 6.67
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R910_GF256", 20, 40, 0.3, 4, 3.7, 1, state=True)      # D20's first frame, first sweeps
+
+
+def test_decode_gf256_dc10_vs_oracle(pkg, orc):
+    """dc = 10 over GF(256) (Ahmed_64800_R45_GF256; the dc 9..16 path was tested at dc = 12 only); traces D10 / D10b."""
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R45_GF256", 20, 40, 0.3, 10, 3.0, 1, state=True)
 
 
 def test_decode_full_alist_code_vs_oracle(pkg, orc):
@@ -654,7 +680,8 @@ def _run_ems_sim(pkg, args, batch, cwd):
     return tr
 
 
-@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8)])
+@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8),
+                                        ("D20", 3), ("D20b", 2), ("D10", 3), ("D10b", 3), ("W1", 64), ("W2", 50), ("W3", 33)])
 def test_c_harness_reproduces_reference_traces(pkg, kat, tmp_path, name, batch):
     """The C Monte-Carlo harness (same argv as the reference) on the GPU prints the reference's trace."""
     k = kat[name]
