@@ -1380,13 +1380,22 @@ int ems_suggest_batch(const ems_code_desc *c, const ems_params *prm, int device,
     if (n_cu <= 0) n_cu = 256;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const int dc = c->rowDegree[0], q = c->GF, logq = ilog2(q);
+    // the degree and the regularity as ems_create sees them: an irregular code, or a degree above 16, runs a one-visit generic kernel
+    int dc = 0;
+    bool regular = true;
+    for (int m = 0; m < c->M; ++m) {
+        dc = std::max(dc, c->rowDegree[m]);
+        regular = regular && c->rowDegree[m] == c->rowDegree[0];
+    }
+    const int q = c->GF, logq = ilog2(q);
+    const bool generic_only = !regular || dc > 16;
     EmsPlan P{};
     P.q = q; P.dc = dc; P.nm = prm->nm; P.nbOper = prm->nbOper; P.M = c->M; P.n_pairs = 1;
     // per-frame state of one handle: APP rows, C->V records, decisions, noisy samples, codewords, counters
     const size_t per_frame = (size_t)c->N * q * 4 + (size_t)c->nbBranch * ems_rec_bytes(prm->nm) + (size_t)c->N * (1 + 4 * logq + 4) + 16;
     long fpc;
     if (per_frame < (1u << 20)) fpc = 32;                         // short codes: state lives in the caches, waves are what they want (N = 96: 8192 frames)
+    else if (generic_only) fpc = 1;                               // one workgroup of the generic kernel per CU
     else if (ems_has_dual_kernel(P)) fpc = dc == 8 ? 1 : 6;       // GF(16) dc 8: flat from 256 to 2048 frames; GF(256) dc 4: six 2-wave workgroups per CU
     else fpc = ems_lpe_for(dc) == 16 ? 3 : 1;                     // one-visit kernels: three 4-wave workgroups per CU (dc <= 4), else one workgroup per CU
     long b = fpc * n_cu;

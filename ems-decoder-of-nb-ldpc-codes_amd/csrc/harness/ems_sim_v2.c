@@ -77,7 +77,10 @@ int main(int argc, char *argv[])
     ems_code_desc desc = {N, M, code.GF, logGF, code.nbBranch, code.rowDegree, col, coef};
     ems_params prm = {nbMax, NbOper, offset, NbIterMax, 1};
     int rc, batch = getenv("EMS_BATCH") ? atoi(getenv("EMS_BATCH")) : 0;
-    if (batch <= 0 && (rc = ems_suggest_batch(&desc, &prm, device, 1, &batch))) die("ems_suggest_batch", rc);
+    /* ems_suggest_batch budgets the main path's per-frame state (APP rows + C->V records, ~10.5 MB for the 64800-bit GF(256) code); the v2
+     * flavour allocates four more [N][q] blocks and the message records per frame on top (ems_core.cpp: v2_prepare, ~4.6 x): ask for the
+     * share of five handles so that the HBM cap of the suggestion holds for this flavour too */
+    if (batch <= 0 && (rc = ems_suggest_batch(&desc, &prm, device, 5, &batch))) die("ems_suggest_batch", rc);
     if (batch > NbMonteCarlo) batch = NbMonteCarlo;
     if (batch < 1) batch = 1;
     ems_handle *h;
