@@ -186,6 +186,9 @@ struct ems_handle {
     std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
     DevBuf<int> d_row_ptr, d_t_dc, d_t_e0;
     std::vector<int> p_cn, p_vn, p_lh, p_pred, p_task;   // check nodes in pairs (k_decode_dual), see build_pairs; p_task: task index per (pair, member), -1 = none
+    std::vector<int> g_cn, g_vn, g_lh, g_pred;   // check nodes in groups of 16 (k_decode_q16t), see build_groups
+    int n_groups = 0;
+    DevBuf<int> d_g_cn, d_g_vn, d_g_lh, d_g_pred;
     std::vector<int> v2_p_dst, v2_p_last;
     int n_pairs = 0;   // iso_vn: variable nodes no check node touches
     std::vector<uint8_t> cn_lh, i2b, b2i;
@@ -217,6 +220,7 @@ struct ems_handle {
     EmsPlan plan{};
     ems_tuning tune{-1, -1, 0, -1};     // launch-shape overrides (ems_set_tuning; initialised from EMS_DUAL / EMS_WAVES / EMS_OCC4 / EMS_TWIN at create)
     bool pair_order = true;             // EMS_PAIR_ORDER=0 (create time): keep the pairs in discovery order
+    bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
     std::string last_kernel;            // what the last ems_decode / ems_v2_decode launched
@@ -336,6 +340,43 @@ void build_pairs(ems_handle *h)
     }
 }
 
+// Groups for the lane-serial GF(16) kernel (k_decode_q16t): up to 16 check nodes per group, mutually independent, every predecessor of a
+// member in an EARLIER group.  Tasks are walked in dependency (level) order and each goes to the first group behind all its predecessors'
+// groups that still has a free slot; group i then depends only on groups < i, which is all the claim-in-order scheduler needs.
+void build_groups(ems_handle *h)
+{
+    const int M = h->M, dc = h->dc, G = 16;
+    std::vector<int> group_of(M, -1), fill;
+    int first_open = 0;                                         // every group before this one is full
+    for (int i = 0; i < M; ++i) {
+        int g = first_open;
+        for (int k = 0; k < dc; ++k) {
+            const int pr = h->t_pred[(size_t)i * dc + k];
+            if (pr >= 0) g = std::max(g, group_of[pr] + 1);
+        }
+        while (g < (int)fill.size() && fill[g] >= G) ++g;
+        if (g >= (int)fill.size()) fill.resize(g + 1, 0);
+        group_of[i] = g;
+        ++fill[g];
+        while (first_open < (int)fill.size() && fill[first_open] >= G) ++first_open;
+    }
+    const int NG = (int)fill.size();
+    h->n_groups = NG;
+    h->g_cn.assign((size_t)NG * G, -1);
+    h->g_vn.assign((size_t)NG * G * dc, 0); h->g_lh.assign((size_t)NG * G * dc, 0); h->g_pred.assign((size_t)NG * G * dc, -1);
+    std::vector<int> slot(NG, 0);
+    for (int i = 0; i < M; ++i) {
+        const int g = group_of[i], s = slot[g]++;
+        h->g_cn[(size_t)g * G + s] = h->t_cnp[i] & 0xFFFFFF;
+        for (int k = 0; k < dc; ++k) {
+            const size_t src = (size_t)i * dc + k, dst = ((size_t)g * G + s) * dc + k;
+            h->g_vn[dst] = h->t_vn[src];
+            h->g_lh[dst] = h->t_lh[src];
+            h->g_pred[dst] = h->t_pred[src] < 0 ? -1 : group_of[h->t_pred[src]];
+        }
+    }
+}
+
 int refresh_plan(ems_handle *h)
 {
     const ems_params &p = h->prm;
@@ -351,6 +392,8 @@ int refresh_plan(ems_handle *h)
     P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
     P.t_cn = h->d_t_cnp.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
     P.n_pairs = h->n_pairs; P.dual = 0;
+    P.q16t = 0; P.n_groups = h->n_groups;
+    P.q_cn = h->d_g_cn.p; P.q_vn = h->d_g_vn.p; P.q_lh = h->d_g_lh.p; P.q_pred = h->d_g_pred.p;
     P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
@@ -601,6 +644,7 @@ void ems_destroy(ems_handle *h)
     h->d_v2_msg.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
+    h->d_g_cn.release(); h->d_g_vn.release(); h->d_g_lh.release(); h->d_g_pred.release();
     h->d_fail.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
     for (auto &e : h->ev)
@@ -627,6 +671,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->tune.occ4 = getenv("EMS_OCC4") ? 1 : 0;
         h->tune.twin = env_int("EMS_TWIN", -1);
         h->pair_order = env_int("EMS_PAIR_ORDER", 1) != 0;
+        h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);
@@ -673,6 +718,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     }
     build_tasks(h, c);
     if (h->regular && (h->dc == 4 || h->dc == 8)) build_pairs(h);
+    if (h->regular && h->dc == 8 && h->q == 16) build_groups(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(EMS_EHIP, "hipEventCreate failed"));
@@ -684,6 +730,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)) ||
+        (r = h->d_g_cn.upload(h->g_cn)) || (r = h->d_g_vn.upload(h->g_vn)) || (r = h->d_g_lh.upload(h->g_lh)) || (r = h->d_g_pred.upload(h->g_pred)) ||
         (r = h->d_row_ptr.upload(h->row_ptr)) || (r = h->d_t_dc.upload(h->t_dc)) || (r = h->d_t_e0.upload(h->t_e0)))
         return bail(r);
     if (hipMemset(h->d_fail.p, 0, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&h->fail_host, sizeof(int), hipHostMallocDefault) != hipSuccess)
@@ -799,6 +846,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     P.occ4 = 0;
     P.dual = 0;
     P.twin = 0;
+    P.q16t = 0;
     if (!h->regular || h->wide) return;                         // irregular check degrees / degrees above 16: the generic kernels in the plan's shape
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
@@ -815,6 +863,9 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     const bool no_dual = td == 0;
     if (allow_dual && td > 0 && ems_has_dual_kernel(P)) { go_dual(dual_fit(td)); return; }
     if (h->tune.waves > 0) { P.occ4 = h->tune.occ4 ? 1 : 0; return; }
+    // GF(16) / dc 8 / nm 8 (BASELINE configs[2]): the lane-serial kernel at every batch size, eight waves per frame (LDS: 15.6 KiB per wave);
+    // tuning.dual = 0 falls back to the one-visit kernel, > 0 (above) forces the two-visit one
+    if (allow_dual && !no_dual && h->q16t_ok && ems_has_q16t_kernel(P)) { P.q16t = 1; P.waves_per_wg = 8; return; }
     // dc = 8 (the GF(16) configuration): the elementary steps are most of a visit, so the dual kernel is used at every
     // batch size, with the workgroup the one-visit kernel would have had
     if (allow_dual && !no_dual && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }

@@ -59,6 +59,8 @@ __device__ unsigned long long g_dbg[8];
 #include "kernels/ems_es_q16.inc"
 #include "kernels/ems_cn.inc"
 #include "kernels/ems_decode.inc"
+#include "kernels/ems_q16t_lane.h"
+#include "kernels/ems_q16t.inc"
 #include "kernels/ems_v2.inc"
 #include "kernels/ems_channel.inc"
 #include "kernels/ems_units.inc"
@@ -134,6 +136,18 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const Em
     hipLaunchKernelGGL((k_decode_twin<Q, NM, DC>), dim3((B + 1) / 2), dim3(64), lds, st, P, B);
     return hipGetLastError();
 }
+// GF(16) / dc = 8 / nm = 8 in lane-serial form (k_decode_q16t)
+bool ems_has_q16t_kernel(const EmsPlan &P) { return P.q == 16 && P.dc == 8 && P.nm == 8 && P.nbOper >= 1 && P.n_groups > 0 && P.q_cn != nullptr && P.t_dc == nullptr; }
+size_t ems_q16t_wg_lds_bytes(int n_groups, int waves) { return (size_t)q16t_header_bytes(n_groups) + (size_t)q16t_wave_bytes() * waves; }
+static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
+{
+    g_kname = "k_decode_q16t";
+    const size_t lds = ems_q16t_wg_lds_bytes(P.n_groups, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_q16t, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_decode_q16t, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
 // check degree above 16 (k_decode_wide)
 int ems_wide_lpe(int q) { return wide_lpe(q); }
 size_t ems_wide_wave_lds_bytes(int q, int dc, int nm) { return (size_t)wide_wave_bytes(q, dc, nm); }
@@ -159,6 +173,10 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st, const char
 }
 static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
 {
+    if (P.q16t) {
+        if (!ems_has_q16t_kernel(P) || P.twin || P.dual || P.occ4 || P.wide || P.waves_per_wg < 1 || P.waves_per_wg > 8) return hipErrorInvalidValue;
+        return launch_decode_q16t(P, B, st);
+    }
     if (P.wide) {
         if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > 4 || P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm))
             return hipErrorInvalidValue;

@@ -74,6 +74,13 @@ struct EmsPlan {
     // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)
+    // GF(16) / dc = 8 / nm = 8 in lane-serial form (k_decode_q16t): the check nodes in GROUPS of up to 16 mutually independent ones, group i
+    // depending only on groups < i
+    int q16t, n_groups;     // q16t: launch k_decode_q16t
+    const int *q_cn;        // [n_groups*16]  check node of slot s, or -1
+    const int *q_vn;        // [n_groups*128] variable node of edge (slot * 8 + t); 0 for an empty slot
+    const int *q_lh;        // [n_groups*128] log of its coefficient (0..14)
+    const int *q_pred;      // [n_groups*128] GROUP of the previous visitor of that variable node in this sweep, or -1
     int wide;               // launch k_decode_wide (check degree above 16: the edges of a visit in passes; t_dc / t_e0 always set)
     int twin;               // launch k_decode_twin: one wave per PAIR OF FRAMES, check nodes in reference order (tiny codes)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)

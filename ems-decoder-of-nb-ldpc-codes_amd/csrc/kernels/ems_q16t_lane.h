@@ -1,0 +1,327 @@
+// kernels/ems_q16t_lane.h -- GF(16) / nm = 8 / dc = 8 (BASELINE configs[2]): the check-node visit in LANE-SERIAL form.
+//
+// k_decode_dual<16, 8, 8> spends ~35 wave-instructions per elementary step: 8 (or 16) lanes co-operate on one step's 48 cells and pay
+// for it in butterflies, broadcasts and masked lanes.  Here ONE LANE runs one whole elementary step (bubble_decoder.c:316-593 in its
+// "first occurrence per symbol" closed form, see ems_es_q16.inc) and one lane owns one EDGE of a check node for the row-wise work
+// (NB_LDPC.c:329-374 and :415-450), as straight-line scalar code.  The only thing a lane cannot do in registers is index by a
+// run-time value (symbol -> slot); that goes through a lane-private column of LDS, `scr[slot][lane]`, bank-conflict-free by
+// construction.  64 elementary steps cost one pass of this code, ~7 wave-instructions each.
+//
+// This header is plain C++ on purpose: the same functions compile for the device (k_decode_q16t in ems_q16t.inc, Scr = a column of
+// LDS) and for the host (tests/ctest/test_q16t.cpp, Scr = an array), where they are compared with the oracle's ElementaryStep /
+// CheckPassLogEMS / decode on the CPU -- the lane code is checked without a GPU.
+//
+// Exactness.  Every value that reaches an output is produced by the reference's own float operations (In1[r] + In2[c], Mvc - min,
+// LLR[Stp-1] + offset, Mcv + Mvc).  ORDER is decided on 32-bit keys (value bits with the low four bits replaced by the symbol): two
+// candidates within 16 ulp of each other -- exact ties included -- cannot be told apart that way, and a lane that sees such a pair
+// among the entries that matter, or any other situation the closed form does not decide (listed at each `bad |=`), reports `bad`:
+// the kernel then redoes that check node with the merge-form code of k_decode (process_cn), which follows the reference's rules
+// literally.  Wrong answers are impossible by construction as long as `bad` is conservative; how OFTEN it fires only costs time.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define Q16T_HD __host__ __device__ __forceinline__
+#else
+#define Q16T_HD inline
+#endif
+
+namespace q16t {
+
+constexpr uint32_t LIM = 0x47C34FFFu;        // largest float below 1e5f (0x47C35000): valid values are <= LIM as bit patterns
+constexpr uint32_t SENT = 0x47C35000u;       // 1e5f, the reference's "empty" value (bubble_decoder.c:370-374)
+constexpr uint32_t INF = 0x7F800000u;
+
+Q16T_HD uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+Q16T_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+Q16T_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+Q16T_HD uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// One message list of a check node: 8 values in ascending order (entries past the length hold 1e5) and the 8 symbols as nibbles
+// (entry k in bits 4k..4k+3; inside the check node symbols are binary images, GF addition = XOR).
+struct List {
+    float v[8];
+    uint32_t s;
+};
+
+// ---- sorting networks on 32-bit keys (verified exhaustively by the 0-1 principle in tests/ctest/test_q16t.cpp) ----
+#define Q16T_CE(a, b) do { const uint32_t lo_ = umin(k[a], k[b]), hi_ = umax(k[a], k[b]); k[a] = lo_; k[b] = hi_; } while (0)
+Q16T_HD void sort8(uint32_t *k)     // optimal 19-comparator network
+{
+    Q16T_CE(0, 1); Q16T_CE(2, 3); Q16T_CE(4, 5); Q16T_CE(6, 7);
+    Q16T_CE(0, 2); Q16T_CE(1, 3); Q16T_CE(4, 6); Q16T_CE(5, 7);
+    Q16T_CE(1, 2); Q16T_CE(5, 6); Q16T_CE(0, 4); Q16T_CE(3, 7);
+    Q16T_CE(1, 5); Q16T_CE(2, 6);
+    Q16T_CE(1, 4); Q16T_CE(3, 6);
+    Q16T_CE(2, 4); Q16T_CE(3, 5);
+    Q16T_CE(3, 4);
+}
+// k[0..15] -> k[0..7] = the 8 smallest in ascending order; returns the 9th smallest
+Q16T_HD uint32_t top8of16(uint32_t *k)
+{
+    sort8(k);
+    sort8(k + 8);
+    uint32_t h = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {              // the 8 smallest = min(A[i], B[7-i]) (a bitonic sequence), the rest = the max's
+        const uint32_t a0 = k[i], b0 = k[15 - i], a1 = k[7 - i], b1 = k[8 + i];
+        k[i] = umin(a0, b0);
+        k[7 - i] = umin(a1, b1);
+        h = umin(h, umin(umax(a0, b0), umax(a1, b1)));
+    }
+    Q16T_CE(0, 4); Q16T_CE(1, 5); Q16T_CE(2, 6); Q16T_CE(3, 7);      // bitonic merge of 8
+    Q16T_CE(0, 2); Q16T_CE(1, 3); Q16T_CE(4, 6); Q16T_CE(5, 7);
+    Q16T_CE(0, 1); Q16T_CE(2, 3); Q16T_CE(4, 5); Q16T_CE(6, 7);
+    return h;
+}
+#undef Q16T_CE
+
+// two of the sorted keys s[0..7], s8 have the same value bits above the symbol nibble (closer than 16 ulp, or equal): their order is
+// not decided here.  Invalid keys (all ones) never match a valid one (valid value bits are <= LIM).
+Q16T_HD bool near_tie9(const uint32_t *s, uint32_t s8)
+{
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) m = umin(m, (s[j] ^ s[j + 1]) | (s[j] == 0xFFFFFFFFu ? 16u : 0u));
+    m = umin(m, (s[7] ^ s8) | (s[7] == 0xFFFFFFFFu ? 16u : 0u));
+    return m < 16u;
+}
+
+// number of cells of the L-shaped region (rows 0..3 x columns 0..7, rows 4..7 x columns 0..3) whose value is <= T (strict = false) or
+// < T (strict = true).  Values are the reference's In1[r] + In2[c]; T is a valid value (0 <= T < 1e5).
+template <bool STRICT> Q16T_HD int count_cells(const List &A, const List &B, float T)
+{
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < (r < 4 ? 8 : 4); ++c) {
+            const float v = A.v[r] + B.v[c];
+            n += STRICT ? (v < T ? 1 : 0) : (v <= T ? 1 : 0);
+        }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ElementaryStep (bubble_decoder.c:316-593) for GF(16), nm = 8, by ONE lane.
+// bins: this lane's 16-slot scratch column, all slots INF on entry and on exit (Scr: ld(i), st(i, u), amin(i, u), sync()).
+// Closed form (ems_es_q16.inc has the derivation): bin s = smallest value of a cell with symbol s = the first occurrence of s in the
+// scan; the scan ends after the cheapest boundary cell (row 7 / column 7), value K; the output is the first 8 bins <= K in ascending
+// order, cut by NbOper (the scan's NbOper-th cell).  Returns true when the closed form does not decide this task (see header).
+// ------------------------------------------------------------------------------------------------
+template <typename Scr> Q16T_HD bool es_lane(const List &A, const List &B, int nbOper, Scr &bins, List &out)
+{
+    // ---- the 48 cells: value In1[r] + In2[c] (:386-423), symbol = XOR of the binary images; first occurrence per symbol ----
+    uint32_t sa[8], sb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sa[i] = (A.s >> (4 * i)) & 15u; sb[i] = (B.s >> (4 * i)) & 15u; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < (r < 4 ? 8 : 4); ++c) bins.amin(sa[r] ^ sb[c], f2u(A.v[r] + B.v[c]));
+    // the cell that ends the scan (:506): the cheapest of row 7 and column 7
+    uint32_t kstop = INF;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kstop = umin(kstop, f2u(A.v[7] + B.v[c]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kstop = umin(kstop, f2u(A.v[r] + B.v[7]));
+    const uint32_t klim = umin(kstop, LIM);                                   // (cells >= 1e5 involve an empty source entry, :478)
+    bins.sync();
+    uint32_t m[16], k[16];
+    int D = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        m[i] = bins.ld(i);
+        const bool valid = m[i] <= klim;
+        D += valid ? 1 : 0;
+        k[i] = valid ? ((m[i] & ~15u) | (uint32_t)i) : 0xFFFFFFFFu;
+    }
+    const uint32_t s8 = top8of16(k);
+    bool bad = near_tie9(k, s8);                                              // two first occurrences whose order the keys do not decide
+    int S = D < 8 ? D : 8;
+    // exact values of the outputs (the keys lost four bits): the bins, indexed by symbol
+    uint32_t ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = j < S ? bins.ld((int)(k[j] & 15u)) : SENT;
+    bins.sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bins.st(i, INF);
+    // ---- another cell with the value K that ends the scan: the order of the two would matter when the other one is the first occurrence
+    //      of another symbol (its bin then holds K).  Conservative: more than one boundary cell at K, or a bin at K that is not the
+    //      boundary cell's own. ----
+    if (kstop <= LIM) {
+        int nK = 0;
+        uint32_t symb = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const bool e = f2u(A.v[7] + B.v[c]) == kstop; nK += e ? 1 : 0; symb = e ? (sa[7] ^ sb[c]) : symb; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const bool e = f2u(A.v[r] + B.v[7]) == kstop; nK += e ? 1 : 0; symb = e ? (sa[r] ^ sb[7]) : symb; }
+        int cK = 0;
+        uint32_t symK = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const bool e = m[i] == kstop; cK += e ? 1 : 0; symK = e ? (uint32_t)i : symK; }
+        bad = bad || nK > 1 || cK > 1 || (cK == 1 && symK != symb);
+    }
+    // ---- NbOper (:472): the scan visits N = #{cells <= the last emitted value (or K)} cells; beyond NbOper it stops on its NbOper-th
+    //      cell, before any other stop: what it has emitted by then are the outputs with at most NbOper cells up to and including their
+    //      own -- a prefix.  A cell with the value of the first entry left out could fall on either side of the cut when fewer than
+    //      NbOper cells are strictly below it: undecided. ----
+    const uint32_t xcut = D >= 8 ? ov[7] : klim;
+    const int N = count_cells<false>(A, B, u2f(xcut));
+    if (N > nbOper) {
+        int lo = 0, hi = S;                                                   // S2 = #{r < S: count(ov[r]) <= NbOper}; counts ascend with r
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int mid = (lo + hi) >> 1;
+            uint32_t t = ov[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t = mid == r ? ov[r] : t;
+            const bool fits = lo < hi && count_cells<false>(A, B, u2f(t)) <= nbOper;
+            const bool over = lo < hi && !fits;
+            lo = fits ? mid + 1 : lo;
+            hi = over ? mid : hi;
+        }
+        const int S2 = lo;
+        if (S2 < S) {
+            uint32_t t = ov[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t = S2 == r ? ov[r] : t;
+            bad = bad || count_cells<true>(A, B, u2f(t)) < nbOper;
+        }
+        S = S2;
+    }
+    uint32_t os = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        out.v[j] = u2f(j < S ? ov[j] : SENT);                                  // :370-374 shows through behind the S entries
+        os |= (j < S ? (k[j] & 15u) : 0u) << (4 * j);
+    }
+    out.s = os;
+    return bad || S == 0;                                                     // (S = 0: the reference would index LLR[-1], :264; never seen)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variable-node side of one edge, by ONE lane: top-8 of the 16 Mvc values in ascending order, ties -> lowest symbol
+// (NB_LDPC.c:354-369), normalised to the smallest (:372-373) and rotated by the edge's coefficient (bubble_decoder.c:133-152).
+// mv[g]: Mvc by symbol index.  rot: nibble table, symbol index -> binary image of (symbol x coefficient) (rot_table()).
+// scr: this lane's 16-slot scratch column (contents irrelevant on entry, undefined on exit).
+// Returns true (undecided here) when some value is not in [0, 1e5) as a bit pattern (negative, -0, NaN, >= 1e5: the literal rules of
+// :358-366 apply), when the order of two of the nine smallest is not decided by the keys, or when a normalised value reaches 1e4 (the
+// closed form of the elementary steps needs sums below 1e5).
+// ------------------------------------------------------------------------------------------------
+template <typename Scr> Q16T_HD bool select_lane(const float *mv, uint64_t rot, Scr &scr, List &out)
+{
+    uint32_t k[16], mx = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const uint32_t u = f2u(mv[g]);
+        mx = umax(mx, u);
+        k[g] = (u & ~15u) | (uint32_t)g;
+        scr.st(g, u);
+    }
+    bool bad = mx > LIM;
+    const uint32_t s8 = top8of16(k);
+    bad = bad || near_tie9(k, s8);
+    scr.sync();
+    uint32_t os = 0;
+    float v0 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t g = k[j] & 15u;
+        const float v = u2f(scr.ld((int)g));
+        if (j == 0) v0 = v;
+        out.v[j] = j == 0 ? 0.0f : v - v0;
+        os |= (uint32_t)((rot >> (4 * g)) & 15u) << (4 * j);
+    }
+    out.s = os;
+    bad = bad || !(out.v[7] < 1e4f);
+    scr.sync();
+    return bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Check-node side of one edge, by ONE lane: the output list of the edge -> dense C->V row with the default LLR[Stp-1] + offset
+// (bubble_decoder.c:231-278), APP = Mcv + Mvc (NB_LDPC.c:444-450), Decision (tools.c:312-330).
+// O: the edge's output list (binary images).  irot: nibble table, binary image -> symbol index of (symbol / coefficient).
+// Outputs: napp[16], the record's fields (values as stored, symbols as symbol indices packed 4 bits each, default, count) and the
+// decision.  scr: scratch column.
+// ------------------------------------------------------------------------------------------------
+struct EdgeOut {
+    float napp[16];
+    float val[8];
+    uint32_t syms;       // symbol index of entry k in bits 4k..4k+3
+    float dflt;
+    int cnt, decide;
+};
+template <typename Scr> Q16T_HD void output_lane(const List &O, const float *mvc, float offset, uint64_t irot, Scr &scr, EdgeOut &e)
+{
+    int S = 0;
+    float last = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool valid = f2u(O.v[j]) <= LIM;
+        S += valid ? 1 : 0;
+        last = valid ? O.v[j] : last;                                          // ascending: the last valid one is LLR[Stp-1]
+    }
+    e.cnt = S;
+    e.dflt = last + offset;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) scr.st(g, f2u(e.dflt));
+    scr.sync();
+    uint32_t ps = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t g = (uint32_t)((irot >> (4 * ((O.s >> (4 * j)) & 15u))) & 15u);
+        e.val[j] = O.v[j];
+        ps |= g << (4 * j);
+        if (j < S) scr.st((int)g, f2u(O.v[j]));
+    }
+    e.syms = ps;
+    scr.sync();
+    float lv = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        e.napp[g] = u2f(scr.ld(g)) + mvc[g];
+        lv = g == 0 ? e.napp[0] : (e.napp[g] < lv ? e.napp[g] : lv);
+    }
+    int lg = 15;
+#pragma unroll
+    for (int g = 14; g >= 0; --g) lg = e.napp[g] == lv ? g : lg;                // first strict minimum = the lowest symbol that attains it
+    e.decide = lv < 1e5f ? lg : 0;
+    scr.sync();
+}
+
+// ---- GF(16) helper tables (symbol index 0 = zero, i >= 1 = alpha^(i-1); init.c:65-130) as 16 nibbles in a 64-bit word ----
+// rot_table: symbol index g -> binary image of g x alpha^lh;  irot_table: binary image b -> symbol index of b / alpha^lh
+inline uint64_t rot_table(const uint8_t *i2b, int lh)
+{
+    uint64_t t = 0;
+    for (int g = 1; g < 16; ++g) t |= (uint64_t)i2b[(g - 1 + lh) % 15 + 1] << (4 * g);
+    return t;
+}
+inline uint64_t irot_table(const uint8_t *b2i, int lh)
+{
+    uint64_t t = 0;
+    for (int b = 1; b < 16; ++b) t |= (uint64_t)((b2i[b] - 1 - lh + 15) % 15 + 1) << (4 * b);
+    return t;
+}
+
+// The forward / backward / merge schedule of a dc = 8 check node (bubble_decoder.c:166-227) on 20 list buffers: inputs 0..7, prefixes
+// P(1..6) in 8..13, suffixes S(1..6) in 14..19; merge M(k) overwrites input k + 1 (dead after the stage that makes it: both chains have
+// passed that input, and a stage reads all its operands before it writes).  Output of edge 0 = S(1), of edge 7 = P(6), of edge t = M(t-1).
+Q16T_HD int buf_P(int k) { return k == 0 ? 0 : 7 + k; }
+Q16T_HD int buf_S(int k) { return k == 7 ? 7 : 13 + k; }
+Q16T_HD int buf_out(int t) { return t == 0 ? buf_S(1) : (t == 7 ? buf_P(6) : t); }
+// task `j` (0: forward, 1: backward, 2 / 3: merges) of stage t = 1..6: operands a, b and destination; false = no such task
+Q16T_HD bool stage_task(int t, int j, int &a, int &b, int &o)
+{
+    if (j == 0) { a = buf_P(t - 1); b = t; o = buf_P(t); return true; }
+    if (j == 1) { a = buf_S(8 - t); b = 7 - t; o = buf_S(7 - t); return true; }
+    if (t < 4) return false;
+    const int kk = j == 2 ? 6 - t : t - 1;                                     // lowest k first, as cn_task: k2 = dc-2-t, k1 = t-1
+    a = buf_P(kk); b = buf_S(kk + 2); o = kk + 1;
+    return true;
+}
+
+} // namespace q16t

@@ -321,9 +321,18 @@ def test_decode_gf16_one_visit_per_wave_kernel_vs_oracle(pkg, orc, monkeypatch):
     assert list(it) == [6, 5, 5, 5]
 
 
+def test_decode_gf16_two_visits_per_wave_kernel_vs_oracle(pkg, orc, monkeypatch):
+    """Round 2/3's GF(16) kernel (k_decode_dual<16, 8, 8>) stays reachable (EMS_DUAL=<waves> / tuning.dual): full state, the NbOper cut."""
+    monkeypatch.setenv("EMS_DUAL", "16")
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 2, state=True)
+    _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 6, 0.0, 2, state=True, early_exit=False)
+    for nop in (11, 13, 15, 24):
+        _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, nop, 0.3, 5, 0.0, 1, state=True, early_exit=False)
+
+
 def test_decode_gf16_state_and_fixed_work(pkg, orc):
-    """The GF(16) configuration on its default (two-visits-per-wave) kernel: full APP / C->V state, and a
-    non-converging fixed-work run."""
+    """The GF(16) configuration on its default kernel (round 4: the lane-serial k_decode_q16t; the closed forms of ems_q16t_lane.h with the
+    merge-form redo of the check nodes they do not decide): full APP / C->V state, and a non-converging fixed-work run."""
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 2, state=True)
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 6, 0.0, 2, state=True, early_exit=False)
     # NbOper = nm + 3 (the scan is cut short in one task of eight: the closed form of that cut in the 8-lane stages) and 3 nm (never)
@@ -333,9 +342,9 @@ def test_decode_gf16_state_and_fixed_work(pkg, orc):
 
 @pytest.mark.parametrize("nop", [12, 13, 14, 15, 17, 20, 32])
 def test_decode_gf16_nboper_sweep_vs_oracle(pkg, orc, nop):
-    """The GF(16) two-visits-per-wave kernel under every NbOper around the message size: the closed form of the scan cut by NbOper
-    (es_stage_q16: the prefix of the rank order with at most NbOper cells) against the oracle's literal loop -- one non-converging
-    frame, four sweeps, full APP / C->V state."""
+    """The GF(16) default kernel under every NbOper around the message size: the closed form of the scan cut by NbOper (the prefix of the
+    rank order with at most NbOper cells; q16t::es_lane) against the oracle's literal loop -- one non-converging frame, four sweeps,
+    full APP / C->V state."""
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, nop, 0.3, 5, 0.0, 1, state=True, early_exit=False)
 
 
@@ -432,16 +441,21 @@ def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
     llr[0] = np.round(llr[0])                       # integers: ties everywhere
     llr[1] = np.round(llr[1] * 2) / 2               # half-integers
     llr[2, ::2] = np.round(llr[2, ::2])             # every other node coarse, the rest continuous
-    dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 4, max_batch=3, early_exit=False)
-    dec.load_llr(llr)
-    dec.decode(3)
-    assert dec.last_kernel == "k_decode_dual<16, 8, 8>"
-    d, it, sy = dec.results(3)
-    for b in range(3):
-        ref = o.decode(llr[b], 8, 16, 0.3, 4, early_exit=False, want_state=True)
-        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"]
-        assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes()
-    dec.close()
+    # the default kernel since round 4 is the lane-serial one (k_decode_q16t): on these inputs nearly every check node reports a tie its
+    # 32-bit keys do not decide and is redone by the merge-form visit (q16t_redo_cn) -- the fallback under load; then the two-visit kernel
+    for forced, kernel in ((None, "k_decode_q16t"), (16, "k_decode_dual<16, 8, 8>")):
+        dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 4, max_batch=3, early_exit=False)
+        if forced is not None:
+            dec.set_tuning(dual=forced)
+        dec.load_llr(llr)
+        dec.decode(3)
+        assert dec.last_kernel == kernel
+        d, it, sy = dec.results(3)
+        for b in range(3):
+            ref = o.decode(llr[b], 8, 16, 0.3, 4, early_exit=False, want_state=True)
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"]
+            assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes()
+        dec.close()
 
 
 def test_batch_position_invariance_and_repeatability(pkg, orc):
