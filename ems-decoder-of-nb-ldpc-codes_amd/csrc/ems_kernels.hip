@@ -141,11 +141,17 @@ bool ems_has_q16t_kernel(const EmsPlan &P) { return P.q == 16 && P.dc == 8 && P.
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves) { return (size_t)q16t_header_bytes(n_groups) + (size_t)q16t_wave_bytes() * waves; }
 static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
 {
-    g_kname = "k_decode_q16t";
     const size_t lds = ems_q16t_wg_lds_bytes(P.n_groups, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode_q16t, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_decode_q16t, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipError_t e;
+    if (P.nbOper == 16) {
+        g_kname = "k_decode_q16t<true>";
+        if ((e = set_max_lds(k_decode_q16t<true>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_decode_q16t<true>, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    } else {
+        g_kname = "k_decode_q16t<false>";
+        if ((e = set_max_lds(k_decode_q16t<false>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_decode_q16t<false>, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    }
     return hipGetLastError();
 }
 // check degree above 16 (k_decode_wide)

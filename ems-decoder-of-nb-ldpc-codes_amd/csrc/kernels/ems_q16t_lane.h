@@ -77,30 +77,54 @@ Q16T_HD uint32_t top8of16(uint32_t *k)
 }
 #undef Q16T_CE
 
+// ---- branch-free helpers: on gfx950 a compare that feeds a select costs two instructions plus wait states (the result travels through
+//      an SGPR pair), so validity, counts and selections are done with sign bits, masks and min / max instead ----
+Q16T_HD uint32_t shl1_sign(uint32_t acc, uint32_t x)      // acc << 1 | sign bit of x
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(acc, x, 31);
+#else
+    return (acc << 1) | (x >> 31);
+#endif
+}
+Q16T_HD uint32_t sign_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }             // all ones when bit 31 is set
+Q16T_HD uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // mask ? a : b, bit by bit (v_bfi_b32)
+Q16T_HD int popc(uint32_t x) { return __builtin_popcount(x); }
+
 // two of the sorted keys s[0..7], s8 have the same value bits above the symbol nibble (closer than 16 ulp, or equal): their order is
-// not decided here.  Invalid keys (all ones) never match a valid one (valid value bits are <= LIM).
-Q16T_HD bool near_tie9(const uint32_t *s, uint32_t s8)
+// not decided here.  Invalid keys (all ones) never match a valid one (valid value bits are <= LIM); an invalid s[j] is kept from
+// matching the invalid key behind it by its own sign bit.  Returns the smallest difference (a tie iff < 16).
+Q16T_HD uint32_t near_tie9(const uint32_t *s, uint32_t s8)
 {
     uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) m = umin(m, (s[j] ^ s[j + 1]) | (s[j] == 0xFFFFFFFFu ? 16u : 0u));
-    m = umin(m, (s[7] ^ s8) | (s[7] == 0xFFFFFFFFu ? 16u : 0u));
-    return m < 16u;
+    for (int j = 0; j < 7; ++j) m = umin(m, (s[j] ^ s[j + 1]) | ((s[j] >> 27) & 16u));
+    m = umin(m, (s[7] ^ s8) | ((s[7] >> 27) & 16u));
+    return m;
 }
 
-// number of cells of the L-shaped region (rows 0..3 x columns 0..7, rows 4..7 x columns 0..3) whose value is <= T (strict = false) or
-// < T (strict = true).  Values are the reference's In1[r] + In2[c]; T is a valid value (0 <= T < 1e5).
-template <bool STRICT> Q16T_HD int count_cells(const List &A, const List &B, float T)
+// The L-shaped region of an elementary step: rows 0..3 x columns 0..7 and rows 4..7 x columns 0..3 (nm = 8: 48 cells).  With NbOper = 16
+// a scan never reaches a cell with (r + 1)(c + 1) > 16 -- the cells it dominates come first -- unless exact ties reorder them (checked
+// where it matters): SMALL restricts a loop to the 34 cells that can be reached.
+template <bool SMALL> Q16T_HD constexpr bool cell_in(int r, int c) { return c < (r < 4 ? 8 : 4) && (!SMALL || (r + 1) * (c + 1) <= 16); }
+
+// number of cells whose value In1[r] + In2[c] is <= T (STRICT: < T); T a valid value (0 <= T < 1e5); no NaN / inf among the sums
+template <bool SMALL, bool STRICT> Q16T_HD int count_cells(const List &A, const List &B, float T)
 {
+    uint32_t acc0 = 0, acc1 = 0;
     int n = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < (r < 4 ? 8 : 4); ++c) {
-            const float v = A.v[r] + B.v[c];
-            n += STRICT ? (v < T ? 1 : 0) : (v <= T ? 1 : 0);
-        }
-    return n;
+        for (int c = 0; c < 8; ++c)
+            if (cell_in<SMALL>(r, c)) {
+                const float v = A.v[r] + B.v[c];
+                const uint32_t d = f2u(STRICT ? v - T : T - v);            // STRICT: negative iff v < T; else negative iff v > T
+                if (n < 32) acc0 = shl1_sign(acc0, d); else acc1 = shl1_sign(acc1, d);
+                ++n;
+            }
+    const int neg = popc(acc0) + popc(acc1);
+    return STRICT ? neg : n - neg;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -109,75 +133,74 @@ template <bool STRICT> Q16T_HD int count_cells(const List &A, const List &B, flo
 // Closed form (ems_es_q16.inc has the derivation): bin s = smallest value of a cell with symbol s = the first occurrence of s in the
 // scan; the scan ends after the cheapest boundary cell (row 7 / column 7), value K; the output is the first 8 bins <= K in ascending
 // order, cut by NbOper (the scan's NbOper-th cell).  Returns true when the closed form does not decide this task (see header).
+// SMALL16: NbOper == 16 known at compile time -- only the 34 reachable cells are binned and counted.
 // ------------------------------------------------------------------------------------------------
-template <typename Scr> Q16T_HD bool es_lane(const List &A, const List &B, int nbOper, Scr &bins, List &out)
+template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const List &B, int nbOper, Scr &bins, List &out)
 {
-    // ---- the 48 cells: value In1[r] + In2[c] (:386-423), symbol = XOR of the binary images; first occurrence per symbol ----
+    // ---- the cells: value In1[r] + In2[c] (:386-423), symbol = XOR of the binary images; first occurrence per symbol ----
     uint32_t sa[8], sb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sa[i] = (A.s >> (4 * i)) & 15u; sb[i] = (B.s >> (4 * i)) & 15u; }
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < (r < 4 ? 8 : 4); ++c) bins.amin(sa[r] ^ sb[c], f2u(A.v[r] + B.v[c]));
-    // the cell that ends the scan (:506): the cheapest of row 7 and column 7
-    uint32_t kstop = INF;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) kstop = umin(kstop, f2u(A.v[7] + B.v[c]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) kstop = umin(kstop, f2u(A.v[r] + B.v[7]));
+        for (int c = 0; c < 8; ++c)
+            if (cell_in<SMALL16>(r, c)) bins.amin(sa[r] ^ sb[c], f2u(A.v[r] + B.v[c]));
+    // the cell that ends the scan (:506): the cheapest of row 7 and column 7 -- lists ascend and float addition is monotone, so it is
+    // (7, 0) or (0, 7); `second` = the next candidates, for the tie test below
+    const uint32_t kA = f2u(A.v[7] + B.v[0]), kB = f2u(A.v[0] + B.v[7]);
+    const uint32_t kstop = umin(kA, kB);
+    const uint32_t second = umin(umax(kA, kB), umin(f2u(A.v[7] + B.v[1]), f2u(A.v[1] + B.v[7])));
     const uint32_t klim = umin(kstop, LIM);                                   // (cells >= 1e5 involve an empty source entry, :478)
     bins.sync();
-    uint32_t m[16], k[16];
-    int D = 0;
+    uint32_t k[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        m[i] = bins.ld(i);
-        const bool valid = m[i] <= klim;
-        D += valid ? 1 : 0;
-        k[i] = valid ? ((m[i] & ~15u) | (uint32_t)i) : 0xFFFFFFFFu;
+        const uint32_t m = bins.ld(i);
+        k[i] = ((m & ~15u) | (uint32_t)i) | sign_mask(klim - m);              // a bin above K (or empty): all ones
     }
     const uint32_t s8 = top8of16(k);
-    bool bad = near_tie9(k, s8);                                              // two first occurrences whose order the keys do not decide
-    int S = D < 8 ? D : 8;
+    uint32_t tie = near_tie9(k, s8);                                          // two first occurrences whose order the keys do not decide
+    uint32_t inv = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) inv = shl1_sign(inv, k[j]);
+    int S = 8 - popc(inv);                                                    // valid among the eight smallest = min(D, 8)
     // exact values of the outputs (the keys lost four bits): the bins, indexed by symbol
     uint32_t ov[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ov[j] = j < S ? bins.ld((int)(k[j] & 15u)) : SENT;
+    for (int j = 0; j < 8; ++j) ov[j] = bfi(sign_mask(k[j]), SENT, bins.ld((int)(k[j] & 15u)));
     bins.sync();
 #pragma unroll
     for (int i = 0; i < 16; ++i) bins.st(i, INF);
     // ---- another cell with the value K that ends the scan: the order of the two would matter when the other one is the first occurrence
-    //      of another symbol (its bin then holds K).  Conservative: more than one boundary cell at K, or a bin at K that is not the
-    //      boundary cell's own. ----
-    if (kstop <= LIM) {
-        int nK = 0;
-        uint32_t symb = 0;
+    //      of another symbol (its bin then holds K).  Conservative, on the keys: two boundary cells within 16 ulp of K, or a valid bin
+    //      within 16 ulp of K that is not the boundary cell's own symbol.  (More than eight bins below K: the scan ends on its eighth
+    //      output, strictly below the ninth bin unless `tie` says otherwise.)  No boundary cell below 1e5: no such stop. ----
+    tie = umin(tie, (second ^ kstop) | (((LIM - kstop) >> 27) & 16u));
+    const uint32_t symb = bfi(sign_mask(kB - kA), sa[0] ^ sb[7], sa[7] ^ sb[0]);   // kB < kA: (0, 7) ends the scan
+    const uint32_t kk = (kstop & ~15u) | symb;
+    uint32_t other = 0xFFFFFFFFu;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const bool e = f2u(A.v[7] + B.v[c]) == kstop; nK += e ? 1 : 0; symb = e ? (sa[7] ^ sb[c]) : symb; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const bool e = f2u(A.v[r] + B.v[7]) == kstop; nK += e ? 1 : 0; symb = e ? (sa[r] ^ sb[7]) : symb; }
-        int cK = 0;
-        uint32_t symK = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const bool e = m[i] == kstop; cK += e ? 1 : 0; symK = e ? (uint32_t)i : symK; }
-        bad = bad || nK > 1 || cK > 1 || (cK == 1 && symK != symb);
-    }
+    for (int j = 0; j < 8; ++j) other = umin(other, (k[j] ^ kk) - 1u);             // 0 .. 14: same value bits as K, another symbol
+    bool bad = tie < 16u || other < 15u;
     // ---- NbOper (:472): the scan visits N = #{cells <= the last emitted value (or K)} cells; beyond NbOper it stops on its NbOper-th
     //      cell, before any other stop: what it has emitted by then are the outputs with at most NbOper cells up to and including their
     //      own -- a prefix.  A cell with the value of the first entry left out could fall on either side of the cut when fewer than
     //      NbOper cells are strictly below it: undecided. ----
-    const uint32_t xcut = D >= 8 ? ov[7] : klim;
-    const int N = count_cells<false>(A, B, u2f(xcut));
-    if (N > nbOper) {
+    const uint32_t xcut = bfi(sign_mask(k[7]), klim, ov[7]);
+    // SMALL16: vb = the cheapest cell that cannot be reached ((2,5), (3,4), (4,3), (5,2) dominate at least 17 cells each, every other
+    // such cell is at least one of them): a threshold at or above it has more than 16 cells below it
+    const uint32_t vb = SMALL16 ? umin(umin(f2u(A.v[2] + B.v[5]), f2u(A.v[3] + B.v[4])), umin(f2u(A.v[4] + B.v[3]), f2u(A.v[5] + B.v[2]))) : INF;
+    auto cells_le = [&](uint32_t t) { return count_cells<SMALL16, false>(A, B, u2f(t)) + (SMALL16 && vb <= t ? 64 : 0); };
+    if (cells_le(xcut) > nbOper) {
         int lo = 0, hi = S;                                                   // S2 = #{r < S: count(ov[r]) <= NbOper}; counts ascend with r
-#pragma unroll
+#pragma unroll 1
         for (int it = 0; it < 4; ++it) {
             const int mid = (lo + hi) >> 1;
             uint32_t t = ov[0];
 #pragma unroll
             for (int r = 1; r < 8; ++r) t = mid == r ? ov[r] : t;
-            const bool fits = lo < hi && count_cells<false>(A, B, u2f(t)) <= nbOper;
+            const bool fits = lo < hi && cells_le(t) <= nbOper;
             const bool over = lo < hi && !fits;
             lo = fits ? mid + 1 : lo;
             hi = over ? mid : hi;
@@ -187,15 +210,19 @@ template <typename Scr> Q16T_HD bool es_lane(const List &A, const List &B, int n
             uint32_t t = ov[0];
 #pragma unroll
             for (int r = 1; r < 8; ++r) t = S2 == r ? ov[r] : t;
-            bad = bad || count_cells<true>(A, B, u2f(t)) < nbOper;
+            bad = bad || count_cells<SMALL16, true>(A, B, u2f(t)) + (SMALL16 && vb < t ? 64 : 0) < nbOper;
         }
+        // a cell that "cannot be reached" can be, when exact ties among the cells it dominates let it come early: fewer than NbOper
+        // cells strictly below the cheapest of them, and the scan gets that far
+        if (SMALL16 && vb <= xcut) bad = bad || count_cells<true, true>(A, B, u2f(vb)) < nbOper;
         S = S2;
     }
     uint32_t os = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        out.v[j] = u2f(j < S ? ov[j] : SENT);                                  // :370-374 shows through behind the S entries
-        os |= (j < S ? (k[j] & 15u) : 0u) << (4 * j);
+        const uint32_t keep = sign_mask((uint32_t)(j - S));                   // j < S
+        out.v[j] = u2f(bfi(keep, ov[j], SENT));                               // :370-374 shows through behind the S entries
+        os |= (keep & k[j] & 15u) << (4 * j);
     }
     out.s = os;
     return bad || S == 0;                                                     // (S = 0: the reference would index LLR[-1], :264; never seen)
@@ -222,7 +249,7 @@ template <typename Scr> Q16T_HD bool select_lane(const float *mv, uint64_t rot, 
     }
     bool bad = mx > LIM;
     const uint32_t s8 = top8of16(k);
-    bad = bad || near_tie9(k, s8);
+    bad = bad || near_tie9(k, s8) < 16u;
     scr.sync();
     uint32_t os = 0;
     float v0 = 0.0f;
@@ -256,26 +283,27 @@ struct EdgeOut {
 };
 template <typename Scr> Q16T_HD void output_lane(const List &O, const float *mvc, float offset, uint64_t irot, Scr &scr, EdgeOut &e)
 {
-    int S = 0;
-    float last = 0.0f;
+    uint32_t inv = 0, last = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const bool valid = f2u(O.v[j]) <= LIM;
-        S += valid ? 1 : 0;
-        last = valid ? O.v[j] : last;                                          // ascending: the last valid one is LLR[Stp-1]
+        const uint32_t u = f2u(O.v[j]), im = sign_mask(LIM - u);               // all ones behind the valid prefix (1e5)
+        inv = shl1_sign(inv, LIM - u);
+        last = umax(last, u & ~im);                                            // ascending, non-negative: the largest valid one is LLR[Stp-1]
     }
+    const int S = 8 - popc(inv);
     e.cnt = S;
-    e.dflt = last + offset;
+    e.dflt = u2f(last) + offset;
 #pragma unroll
     for (int g = 0; g < 16; ++g) scr.st(g, f2u(e.dflt));
     scr.sync();
     uint32_t ps = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t g = (uint32_t)((irot >> (4 * ((O.s >> (4 * j)) & 15u))) & 15u);
+    for (int j = 7; j >= 0; --j) {                                             // descending: an entry behind the prefix (symbol nibble 0) writes the
+        const uint32_t g = (uint32_t)((irot >> (4 * ((O.s >> (4 * j)) & 15u))) & 15u);   // default first, the valid entries overwrite it
+        const uint32_t u = f2u(O.v[j]);
         e.val[j] = O.v[j];
         ps |= g << (4 * j);
-        if (j < S) scr.st((int)g, f2u(O.v[j]));
+        scr.st((int)g, bfi(sign_mask(LIM - u), f2u(e.dflt), u));
     }
     e.syms = ps;
     scr.sync();

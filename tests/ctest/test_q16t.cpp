@@ -4,7 +4,7 @@
 // coarse / short lists, and whole decodes of the 64800-bit GF(16) code where every check node goes through select_lane -> 18 x
 // es_lane -> output_lane (a check node that reports `bad` takes the oracle's CheckPassLogEMS instead, as the kernel falls back to the
 // merge-form code).  Exit code 0 = everything bit-exact and the fallback rate is small.
-//   usage: test_q16t <matrix> [frames] [EbN0] [sweeps]
+//   usage: test_q16t <matrix> [frames] [EbN0] [sweeps] [NbOper]      (Q16T_GENERIC=1: the 48-cell form even at NbOper = 16)
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -90,7 +90,8 @@ static int check_es(const orc_gf *gf, long trials, int *n_bad_cont)
         HostScr bins;
         for (int i = 0; i < 16; ++i) bins.a[i] = INF;
         List out;
-        const bool bad = es_lane(to_list(va, ga, gf), to_list(vb, gb, gf), nop, bins, out);
+        const bool bad = (nop == 16 && (it & 16)) ? es_lane<true>(to_list(va, ga, gf), to_list(vb, gb, gf), nop, bins, out)
+                                                   : es_lane<false>(to_list(va, ga, gf), to_list(vb, gb, gf), nop, bins, out);
         for (int i = 0; i < 16; ++i) if (bins.a[i] != INF) { printf("bins not restored\n"); return 1; }
         if (kind < 5) { ++tot_cont; bad_cont += bad; }
         bad_all += bad;
@@ -126,7 +127,8 @@ int main(int argc, char **argv)
     const int frames = argc > 2 ? atoi(argv[2]) : 2;
     const float EbN = argc > 3 ? (float)atof(argv[3]) : 1.5f;
     const int itmax = (argc > 4 ? atoi(argv[4]) : 5) + 1;
-    const int nm = 8, nop = 16, q = 16, N = c->N, M = c->M, E = c->E;
+    const int nm = 8, nop = argc > 5 ? atoi(argv[5]) : 16, q = 16, N = c->N, M = c->M, E = c->E;
+    const bool small16 = nop == 16 && !getenv("Q16T_GENERIC");
     const float offset = 0.3f;
     orc_encoder *enc = orc_encoder_create(c, &gf);
     orc_rng rng = {0};
@@ -163,7 +165,7 @@ int main(int argc, char **argv)
                         if (!stage_task(st, j, a, b, o)) continue;
                         in[nt][0] = L[a]; in[nt][1] = L[b]; dst[nt] = o; ++nt;         // a stage reads all its operands before it writes
                     }
-                    for (int j = 0; j < nt; ++j) bad = es_lane(in[j][0], in[j][1], nop, scr, out[j]) || bad;
+                    for (int j = 0; j < nt; ++j) bad = (small16 ? es_lane<true>(in[j][0], in[j][1], nop, scr, out[j]) : es_lane<false>(in[j][0], in[j][1], nop, scr, out[j])) || bad;
                     for (int j = 0; j < nt; ++j) L[dst[j]] = out[j];
                 }
                 ++cn_total;
