@@ -221,6 +221,7 @@ struct ems_handle {
     ems_tuning tune{-1, -1, 0, -1};     // launch-shape overrides (ems_set_tuning; initialised from EMS_DUAL / EMS_WAVES / EMS_OCC4 / EMS_TWIN at create)
     bool pair_order = true;             // EMS_PAIR_ORDER=0 (create time): keep the pairs in discovery order
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
+    int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
     std::string last_kernel;            // what the last ems_decode / ems_v2_decode launched
@@ -672,6 +673,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->tune.twin = env_int("EMS_TWIN", -1);
         h->pair_order = env_int("EMS_PAIR_ORDER", 1) != 0;
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
+        h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);
@@ -863,9 +865,14 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     const bool no_dual = td == 0;
     if (allow_dual && td > 0 && ems_has_dual_kernel(P)) { go_dual(dual_fit(td)); return; }
     if (h->tune.waves > 0) { P.occ4 = h->tune.occ4 ? 1 : 0; return; }
-    // GF(16) / dc 8 / nm 8 (BASELINE configs[2]): the lane-serial kernel at every batch size, eight waves per frame (LDS: 15.6 KiB per wave);
+    // GF(16) / dc 8 / nm 8 (BASELINE configs[2]): the lane-serial kernel at every batch size, twelve waves per frame (LDS: 12.1 KiB per wave);
     // tuning.dual = 0 falls back to the one-visit kernel, > 0 (above) forces the two-visit one
-    if (allow_dual && !no_dual && h->q16t_ok && ems_has_q16t_kernel(P)) { P.q16t = 1; P.waves_per_wg = 8; return; }
+    if (allow_dual && !no_dual && h->q16t_ok && ems_has_q16t_kernel(P)) {
+        int waves = h->q16t_waves > 0 ? std::min(h->q16t_waves, ems_q16t_max_waves()) : ems_q16t_max_waves();
+        while (waves > 1 && ems_q16t_wg_lds_bytes(P.n_groups, waves) > lds_cap) --waves;
+        P.q16t = 1; P.waves_per_wg = waves;
+        return;
+    }
     // dc = 8 (the GF(16) configuration): the elementary steps are most of a visit, so the dual kernel is used at every
     // batch size, with the workgroup the one-visit kernel would have had
     if (allow_dual && !no_dual && h->dc == 8 && ems_has_dual_kernel(P)) { go_dual(dual_fit(P.waves_per_wg)); return; }

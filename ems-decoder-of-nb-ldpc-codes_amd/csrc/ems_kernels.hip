@@ -138,6 +138,7 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const Em
 }
 // GF(16) / dc = 8 / nm = 8 in lane-serial form (k_decode_q16t)
 bool ems_has_q16t_kernel(const EmsPlan &P) { return P.q == 16 && P.dc == 8 && P.nm == 8 && P.nbOper >= 1 && P.n_groups > 0 && P.q_cn != nullptr && P.t_dc == nullptr; }
+int ems_q16t_max_waves() { return EMS_Q16T_WAVES; }
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves) { return (size_t)q16t_header_bytes(n_groups) + (size_t)q16t_wave_bytes() * waves; }
 static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
 {
@@ -180,7 +181,7 @@ hipError_t ems_launch_decode(const EmsPlan &P, int B, hipStream_t st, const char
 static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
 {
     if (P.q16t) {
-        if (!ems_has_q16t_kernel(P) || P.twin || P.dual || P.occ4 || P.wide || P.waves_per_wg < 1 || P.waves_per_wg > 8) return hipErrorInvalidValue;
+        if (!ems_has_q16t_kernel(P) || P.twin || P.dual || P.occ4 || P.wide || P.waves_per_wg < 1 || P.waves_per_wg > EMS_Q16T_WAVES) return hipErrorInvalidValue;
         return launch_decode_q16t(P, B, st);
     }
     if (P.wide) {

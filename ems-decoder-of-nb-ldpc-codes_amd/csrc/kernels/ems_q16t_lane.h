@@ -90,6 +90,11 @@ Q16T_HD uint32_t shl1_sign(uint32_t acc, uint32_t x)      // acc << 1 | sign bit
 Q16T_HD uint32_t sign_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }             // all ones when bit 31 is set
 Q16T_HD uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // mask ? a : b, bit by bit (v_bfi_b32)
 Q16T_HD int popc(uint32_t x) { return __builtin_popcount(x); }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(Q16T_MARKS)
+#define Q16T_MARK(n) asm volatile("; Q16T_MARK " #n)
+#else
+#define Q16T_MARK(n) do { } while (0)
+#endif
 
 // two of the sorted keys s[0..7], s8 have the same value bits above the symbol nibble (closer than 16 ulp, or equal): their order is
 // not decided here.  Invalid keys (all ones) never match a valid one (valid value bits are <= LIM); an invalid s[j] is kept from
@@ -138,6 +143,7 @@ template <bool SMALL, bool STRICT> Q16T_HD int count_cells(const List &A, const 
 template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const List &B, int nbOper, Scr &bins, List &out)
 {
     // ---- the cells: value In1[r] + In2[c] (:386-423), symbol = XOR of the binary images; first occurrence per symbol ----
+    Q16T_MARK(es_cells);
     uint32_t sa[8], sb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sa[i] = (A.s >> (4 * i)) & 15u; sb[i] = (B.s >> (4 * i)) & 15u; }
@@ -153,22 +159,28 @@ template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const 
     const uint32_t second = umin(umax(kA, kB), umin(f2u(A.v[7] + B.v[1]), f2u(A.v[1] + B.v[7])));
     const uint32_t klim = umin(kstop, LIM);                                   // (cells >= 1e5 involve an empty source entry, :478)
     bins.sync();
+    Q16T_MARK(es_keys);
     uint32_t k[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t m = bins.ld(i);
-        k[i] = ((m & ~15u) | (uint32_t)i) | sign_mask(klim - m);              // a bin above K (or empty): all ones
-    }
+    for (int i = 0; i < 16; ++i) k[i] = (bins.ld(i) & ~15u) | (uint32_t)i;   // (a bin above K, or empty, sorts behind every valid one as it is)
+    Q16T_MARK(es_sort);
     const uint32_t s8 = top8of16(k);
-    uint32_t tie = near_tie9(k, s8);                                          // two first occurrences whose order the keys do not decide
-    uint32_t inv = 0;
+    Q16T_MARK(es_post);
+    const uint32_t kmax = klim | 15u;                                         // a sorted key is valid (its bin <= K) iff it is <= kmax
+    uint32_t vm[8], inv = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) inv = shl1_sign(inv, k[j]);
+    for (int j = 0; j < 8; ++j) { vm[j] = sign_mask(kmax - k[j]); inv = shl1_sign(inv, kmax - k[j]); }   // vm: all ones = not valid
     int S = 8 - popc(inv);                                                    // valid among the eight smallest = min(D, 8)
+    // two first occurrences whose order the keys do not decide: same value bits above the symbol nibble (an invalid key is kept from
+    // matching the one behind it)
+    uint32_t tie = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) tie = umin(tie, (k[j] ^ k[j + 1]) | (vm[j] & 16u));
+    tie = umin(tie, (k[7] ^ s8) | (vm[7] & 16u));
     // exact values of the outputs (the keys lost four bits): the bins, indexed by symbol
     uint32_t ov[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ov[j] = bfi(sign_mask(k[j]), SENT, bins.ld((int)(k[j] & 15u)));
+    for (int j = 0; j < 8; ++j) ov[j] = bfi(vm[j], SENT, bins.ld((int)(k[j] & 15u)));
     bins.sync();
 #pragma unroll
     for (int i = 0; i < 16; ++i) bins.st(i, INF);
@@ -176,8 +188,9 @@ template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const 
     //      of another symbol (its bin then holds K).  Conservative, on the keys: two boundary cells within 16 ulp of K, or a valid bin
     //      within 16 ulp of K that is not the boundary cell's own symbol.  (More than eight bins below K: the scan ends on its eighth
     //      output, strictly below the ninth bin unless `tie` says otherwise.)  No boundary cell below 1e5: no such stop. ----
+    Q16T_MARK(es_ktest);
     tie = umin(tie, (second ^ kstop) | (((LIM - kstop) >> 27) & 16u));
-    const uint32_t symb = bfi(sign_mask(kB - kA), sa[0] ^ sb[7], sa[7] ^ sb[0]);   // kB < kA: (0, 7) ends the scan
+    const uint32_t symb = bfi(sign_mask(kB - kA), (A.s ^ (B.s >> 28)) & 15u, ((A.s >> 28) ^ B.s) & 15u);   // kB < kA: (0, 7) ends the scan, else (7, 0)
     const uint32_t kk = (kstop & ~15u) | symb;
     uint32_t other = 0xFFFFFFFFu;
 #pragma unroll
@@ -187,12 +200,14 @@ template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const 
     //      cell, before any other stop: what it has emitted by then are the outputs with at most NbOper cells up to and including their
     //      own -- a prefix.  A cell with the value of the first entry left out could fall on either side of the cut when fewer than
     //      NbOper cells are strictly below it: undecided. ----
-    const uint32_t xcut = bfi(sign_mask(k[7]), klim, ov[7]);
+    Q16T_MARK(es_count);
+    const uint32_t xcut = bfi(vm[7], klim, ov[7]);
     // SMALL16: vb = the cheapest cell that cannot be reached ((2,5), (3,4), (4,3), (5,2) dominate at least 17 cells each, every other
     // such cell is at least one of them): a threshold at or above it has more than 16 cells below it
     const uint32_t vb = SMALL16 ? umin(umin(f2u(A.v[2] + B.v[5]), f2u(A.v[3] + B.v[4])), umin(f2u(A.v[4] + B.v[3]), f2u(A.v[5] + B.v[2]))) : INF;
     auto cells_le = [&](uint32_t t) { return count_cells<SMALL16, false>(A, B, u2f(t)) + (SMALL16 && vb <= t ? 64 : 0); };
     if (cells_le(xcut) > nbOper) {
+        Q16T_MARK(es_ovf);
         int lo = 0, hi = S;                                                   // S2 = #{r < S: count(ov[r]) <= NbOper}; counts ascend with r
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
@@ -217,6 +232,7 @@ template <bool SMALL16, typename Scr> Q16T_HD bool es_lane(const List &A, const 
         if (SMALL16 && vb <= xcut) bad = bad || count_cells<true, true>(A, B, u2f(vb)) < nbOper;
         S = S2;
     }
+    Q16T_MARK(es_out);
     uint32_t os = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -335,11 +351,15 @@ inline uint64_t irot_table(const uint8_t *b2i, int lh)
     return t;
 }
 
-// The forward / backward / merge schedule of a dc = 8 check node (bubble_decoder.c:166-227) on 20 list buffers: inputs 0..7, prefixes
-// P(1..6) in 8..13, suffixes S(1..6) in 14..19; merge M(k) overwrites input k + 1 (dead after the stage that makes it: both chains have
-// passed that input, and a stage reads all its operands before it writes).  Output of edge 0 = S(1), of edge 7 = P(6), of edge t = M(t-1).
-Q16T_HD int buf_P(int k) { return k == 0 ? 0 : 7 + k; }
-Q16T_HD int buf_S(int k) { return k == 7 ? 7 : 13 + k; }
+// The forward / backward / merge schedule of a dc = 8 check node (bubble_decoder.c:166-227) on 14 list buffers.  A stage reads all its
+// operands before it writes, so a result may take the buffer of a list whose last reader is that same stage:
+//   inputs in(t) = 0..7; merge M(k) overwrites in(k + 1) (both chains have passed that input by the stage that makes M(k));
+//   prefixes P(1) P(2) P(3) = 8 9 10, then P(4) -> 9 (P(2) is last read by M(2) in stage 4), P(5) -> 10, P(6) -> 8;
+//   suffixes S(6) S(5) S(4) = 11 12 13, then S(3) -> 12 (S(5) is last read by M(3) in stage 4), S(2) -> 13, S(1) -> 11.
+// Output of edge 0 = S(1), of edge 7 = P(6), of edge t = M(t-1).  (tests/ctest/test_q16t.cpp runs whole decodes through this table.)
+constexpr int NBUF = 14;
+Q16T_HD int buf_P(int k) { return k == 0 ? 0 : (k == 1 || k == 6 ? 8 : (k == 2 || k == 4 ? 9 : 10)); }
+Q16T_HD int buf_S(int k) { return k == 7 ? 7 : (k == 6 || k == 1 ? 11 : (k == 5 || k == 3 ? 12 : 13)); }
 Q16T_HD int buf_out(int t) { return t == 0 ? buf_S(1) : (t == 7 ? buf_P(6) : t); }
 // task `j` (0: forward, 1: backward, 2 / 3: merges) of stage t = 1..6: operands a, b and destination; false = no such task
 Q16T_HD bool stage_task(int t, int j, int &a, int &b, int &o)

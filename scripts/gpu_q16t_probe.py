@@ -27,11 +27,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
     rs = np.random.RandomState(1)
     sigma = o.sigma(0.0)
     noisy = (1.0 + sigma * rs.randn(B, code.N, code.logGF)).astype(np.float32)
-    for env in ("1", "0"):
+    for env, wv in (("1", "12"), ("1", "10"), ("1", "8"), ("0", "0")):
         os.environ["EMS_Q16T"] = env
+        os.environ["EMS_Q16T_WAVES"] = wv
         dec = pkg.Decoder(code, 8, 16, 0.3, 30, max_batch=B, early_exit=False)
         ts = []
         for rep in range(3):
             dec.llr_init(noisy, sigma); dec.decode(B); dec.synchronize(); ts.append(dec.last_decode_ms)
-        say("EMS_Q16T=%s kernel %s: decode ms %s -> %.1f frames/s" % (env, dec.last_kernel, ["%.2f" % t for t in ts], B / min(ts) * 1e3))
+        say("EMS_Q16T=%s waves %d kernel %s: decode ms %s -> %.1f frames/s" % (env, dec.last_workgroup_waves, dec.last_kernel, ["%.2f" % t for t in ts], B / min(ts) * 1e3))
         dec.close()

@@ -149,7 +149,7 @@ int main(int argc, char **argv)
             for (int m = 0; m < M; ++m) {
                 const int e0 = c->row_ptr[m];
                 float mvc[8][16];
-                List L[20];
+                List L[NBUF];
                 bool bad = false;
                 for (int t = 0; t < 8; ++t) {
                     const float *a = &app[(size_t)c->col[e0 + t] * q], *cv = &ctov[(size_t)(e0 + t) * q];

@@ -443,7 +443,7 @@ def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
     llr[2, ::2] = np.round(llr[2, ::2])             # every other node coarse, the rest continuous
     # the default kernel since round 4 is the lane-serial one (k_decode_q16t): on these inputs nearly every check node reports a tie its
     # 32-bit keys do not decide and is redone by the merge-form visit (q16t_redo_cn) -- the fallback under load; then the two-visit kernel
-    for forced, kernel in ((None, "k_decode_q16t"), (16, "k_decode_dual<16, 8, 8>")):
+    for forced, kernel in ((None, "k_decode_q16t<true>"), (16, "k_decode_dual<16, 8, 8>")):
         dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 4, max_batch=3, early_exit=False)
         if forced is not None:
             dec.set_tuning(dual=forced)
