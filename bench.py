@@ -45,6 +45,10 @@ WORKLOADS = {
     "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1536),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
+    # full-size codes outside the BASELINE list, on the generic kernels (side lines): irregular check degrees 3 / 4 / 5 (SURVEY.md 8(f) f4;
+    # tests/golden/make_irregular_big.py) and the reference's dc = 20 matrix (k_decode_wide)
+    "irr345": ("Irr345_N8100_M4050_GF256", 20, 40, 0.3, 30, 1.0, 256),
+    "dc20": ("Ahmed_64800_R910_GF256", 20, 40, 0.3, 30, 3.0, 256),
     # v2 flavour: same code and message size, NbIterMax 28 = 29 iterations (iter = 0..NbIterMax,
     # v2.c:2119); inputs are seeded synthetic max-is-best likelihoods (synthetic_likelihood below, sigma 0.95)
     "gf256_v2": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 28, None, 1536),
@@ -437,7 +441,7 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
 
     # ---- side figure (never `value`): early exit enabled at the operating point of SURVEY.md 8(d) ----
     oper = None
-    OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}[workload]
+    OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}.get(workload, 3.0)
     if side_figures and rank == 0 and world == 1 and not a.synthetic_zero_codeword:
         nd = min(256, B)
         with c_stdout_to_stderr():
@@ -721,9 +725,10 @@ def main():
     # ---- the other BASELINE configurations (configs[1] and [2]) at their own batch, a few steps each: driver-timed side lines ----
     others = {}
     if a.workload == "gf256" and world == 1 and not a.no_other_workloads:
-        for w in ("gf16", "n96"):
-            r = run_decode_workload(a, pkg, harness, ge, torch, None, rank, 1, local, w, WORKLOADS[w][6], 5, 2, side_figures=False)
-            others[w] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": 5, "warmup": 2, "workload": r["workload"],
+        for w in ("gf16", "n96", "irr345", "dc20"):
+            nst, nwu = (5, 2) if w in ("gf16", "n96") else (2, 1)
+            r = run_decode_workload(a, pkg, harness, ge, torch, None, rank, 1, local, w, WORKLOADS[w][6], nst, nwu, side_figures=False)
+            others[w] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": nst, "warmup": nwu, "workload": r["workload"],
                          "batch": r["batch_per_gpu"], "frames_errframes_biterrs_undetected_sumiter": r["counters"],
                          "counters_match_golden": r["counters_match_golden"], "roofline": r["roofline"]}
         r = run_v2_workload(a, pkg, ge, torch, None, rank, 1, local, WORKLOADS["gf256_v2"][6], 3, 1)

@@ -222,6 +222,7 @@ struct ems_handle {
     bool pair_order = true;             // EMS_PAIR_ORDER=0 (create time): keep the pairs in discovery order
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
+    bool wide_dc9 = false;              // EMS_WIDE=1 (create time): GF(256) codes with check degree 9..16 on k_decode_wide
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
     std::string last_kernel;            // what the last ems_decode / ems_v2_decode launched
@@ -674,6 +675,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->pair_order = env_int("EMS_PAIR_ORDER", 1) != 0;
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
+        h->wide_dc9 = env_int("EMS_WIDE", 0) != 0;
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);
@@ -701,7 +703,9 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     // Up to 16 edges a check node's edges each own a row of the wavefront's lanes; above that (the reference's Ahmed_64800_R910_GF256 has
     // dc = 20, and it caps the degree nowhere: init.c:320, bubble_decoder.c:166-227) k_decode_wide walks them in passes.
     if (h->dc > EMS_MAX_DC) return bail(fail(EMS_EUNSUPPORTED, "check degree %d: degrees up to %d are built", h->dc, EMS_MAX_DC));
-    h->wide = h->dc > 16;
+    // (dc 9..16 over GF(256): rows of 4 lanes keep 64 symbols per lane -- 256 VGPRs and spills; EMS_WIDE=1 / the default below sends those
+    //  codes through the pass-walking kernel too, rows of 8 lanes in two passes)
+    h->wide = h->dc > 16 || (h->dc > 8 && h->q == 256 && h->wide_dc9);
     if (!h->wide && h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 

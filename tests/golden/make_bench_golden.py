@@ -35,6 +35,8 @@ WORKLOADS = {   # name: (matrix, nm, NbOper, offset, NbIterMax, Eb/N0, frames) -
     "gf256": ("Ahmed_64800_R12_GF256", 20, 40, 0.3, 30, 1.0, 1536),
     "gf16": ("Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 0.0, 256),
     "n96": ("N96_K48_GF64", 16, 32, 0.3, 30, -3.0, 8192),
+    "irr345": ("Irr345_N8100_M4050_GF256", 20, 40, 0.3, 30, 1.0, 256),        # side lines: irregular check degrees, check degree 20
+    "dc20": ("Ahmed_64800_R910_GF256", 20, 40, 0.3, 30, 3.0, 256),
 }
 
 
@@ -113,7 +115,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--ranks":              # e.g. --ranks 1 2 3 4 5 6 7 (18 minutes of 8 cores each)
         add_ranks([int(x) for x in sys.argv[2:]], int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count() or 8))))
         sys.exit(0)
-    which = sys.argv[1:] or list(WORKLOADS)
+    which = sys.argv[1:] or ["gf256", "gf16", "n96"]
     threads = int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count() or 8)))
     gdir = os.path.join(ROOT, "tests", "golden")
     npz = os.path.join(gdir, "bench_golden.npz")
