@@ -219,7 +219,9 @@ struct ems_handle {
     bool have_llr_ev = false, have_dec_ev = false;
     EmsPlan plan{};
     ems_tuning tune{-1, -1, 0, -1};     // launch-shape overrides (ems_set_tuning; initialised from EMS_DUAL / EMS_WAVES / EMS_OCC4 / EMS_TWIN at create)
-    bool pair_order = true;             // EMS_PAIR_ORDER=0 (create time): keep the pairs in discovery order
+    int pair_order = 1;                 // EMS_PAIR_ORDER (create time): 0 keeps the pairs in discovery order, 1 list-schedules them (longest chain
+                                        // first), 2 list-schedules them with a preference for the successors of the pair a wave has just finished
+                                        // (their shared APP rows are then re-read while still in L2: an experiment, see profiles/NOTES.md)
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
     bool wide_dc9 = false;              // EMS_WIDE=1 (create time): GF(256) codes with check degree 9..16 on k_decode_wide
@@ -293,13 +295,24 @@ void build_pairs(ems_handle *h)
             if (!npend[i]) avail.push_back(i);
         const int W = 2;
         double free_at[W] = {0.0, 0.0};
+        int last_of[W] = {-1, -1};                              // the pair each wave has just finished
+        const bool local = h->pair_order == 2;
+        auto follows = [&](int c, int w) {                      // c reads an APP row the wave's last pair has just written
+            if (!local || last_of[w] < 0) return false;
+            return std::binary_search(pp[c].begin(), pp[c].end(), last_of[w]);
+        };
         order.reserve(NP);
         while ((int)order.size() < NP) {
             const int w = free_at[0] <= free_at[1] ? 0 : 1;
             const double now = free_at[w];
             int best = -1;
-            for (int c : avail)                                 // ready now: longest chain first (then list order)
-                if (ready_at[c] <= now && (best < 0 || height[c] > height[best] || (height[c] == height[best] && c < best))) best = c;
+            for (int c : avail) {                               // ready now: (a successor of this wave's last pair first,) longest chain first (then list order)
+                if (ready_at[c] > now) continue;
+                if (best < 0) { best = c; continue; }
+                const bool fc = follows(c, w), fb = follows(best, w);
+                if (fc != fb) { if (fc) best = c; continue; }
+                if (height[c] > height[best] || (height[c] == height[best] && c < best)) best = c;
+            }
             if (best < 0)
                 for (int c : avail)                             // nothing ready: the soonest
                     if (best < 0 || ready_at[c] < ready_at[best] || (ready_at[c] == ready_at[best] && height[c] > height[best])) best = c;
@@ -307,6 +320,7 @@ void build_pairs(ems_handle *h)
             const double start = std::max(now, ready_at[best]);
             fin[best] = start + 1.0;
             free_at[w] = fin[best];
+            last_of[w] = best;
             order.push_back(best);
             for (int sc : succ[best]) {
                 ready_at[sc] = std::max(ready_at[sc], fin[best]);
@@ -366,7 +380,9 @@ void build_groups(ems_handle *h)
     h->n_groups = NG;
     h->g_cn.assign((size_t)NG * G, -1);
     h->g_vn.assign((size_t)NG * G * dc, 0); h->g_lh.assign((size_t)NG * G * dc, 0); h->g_pred.assign((size_t)NG * G * dc, -1);
-    std::vector<int> slot(NG, 0);
+    std::vector<int> slot(NG, 0), last_group(h->N, -1);
+    for (int i = 0; i < M; ++i)                                  // tasks are in dependency order: the last writer of a node is its last visitor of a sweep
+        for (int k = 0; k < dc; ++k) last_group[h->t_vn[(size_t)i * dc + k]] = group_of[i];
     for (int i = 0; i < M; ++i) {
         const int g = group_of[i], s = slot[g]++;
         h->g_cn[(size_t)g * G + s] = h->t_cnp[i] & 0xFFFFFF;
@@ -374,7 +390,8 @@ void build_groups(ems_handle *h)
             const size_t src = (size_t)i * dc + k, dst = ((size_t)g * G + s) * dc + k;
             h->g_vn[dst] = h->t_vn[src];
             h->g_lh[dst] = h->t_lh[src];
-            h->g_pred[dst] = h->t_pred[src] < 0 ? -1 : group_of[h->t_pred[src]];
+            // the previous visitor of this variable node: an earlier group of the same sweep, else the node's last visitor of the sweep before
+            h->g_pred[dst] = h->t_pred[src] >= 0 ? (group_of[h->t_pred[src]] << 1) | 1 : (last_group[h->t_vn[src]] << 1);
         }
     }
 }
@@ -672,7 +689,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->tune.waves = env_int("EMS_WAVES", -1);
         h->tune.occ4 = getenv("EMS_OCC4") ? 1 : 0;
         h->tune.twin = env_int("EMS_TWIN", -1);
-        h->pair_order = env_int("EMS_PAIR_ORDER", 1) != 0;
+        h->pair_order = env_int("EMS_PAIR_ORDER", 1);
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
         h->wide_dc9 = env_int("EMS_WIDE", 0) != 0;

@@ -80,7 +80,8 @@ struct EmsPlan {
     const int *q_cn;        // [n_groups*16]  check node of slot s, or -1
     const int *q_vn;        // [n_groups*128] variable node of edge (slot * 8 + t); 0 for an empty slot
     const int *q_lh;        // [n_groups*128] log of its coefficient (0..14)
-    const int *q_pred;      // [n_groups*128] GROUP of the previous visitor of that variable node in this sweep, or -1
+    const int *q_pred;      // [n_groups*128] the previous visitor of that variable node: (group << 1) | 1 = an earlier group of this sweep,
+                            //                (group << 1) | 0 = none in this sweep: the node's LAST visitor of the sweep before; -1 = empty slot
     int wide;               // launch k_decode_wide (check degree above 16: the edges of a visit in passes; t_dc / t_e0 always set)
     int twin;               // launch k_decode_twin: one wave per PAIR OF FRAMES, check nodes in reference order (tiny codes)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)
