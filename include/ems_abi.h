@@ -63,7 +63,15 @@ void ems_free_code_desc(ems_code_desc *desc);
  * idx2bin[i] = binary image of symbol index i (bit l = BINGF[i][l]); bin2idx = inverse. */
 int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
 
-/* Create a decoder for one code on HIP device `device`, sized for up to max_batch frames in flight. */
+/* Create a decoder for one code on HIP device `device`, sized for up to max_batch frames in flight.
+ * What the kernels are built for, next to what the reference allows (it caps none of these; EMS_EUNSUPPORTED / EMS_EINVAL beyond):
+ *   - field order GF(16), GF(64), GF(256): the reference's own list (init.c:431-435);
+ *   - check degree 2..64, regular or irregular (reference: scratch sized by rowDegree[0], no cap, init.c:320; its matrices go up to 20);
+ *     degrees above 16 walk the edges of a visit in passes (k_decode_wide), LDS permitting: (4 dc - 6) lists of nm + 2 entries per check node;
+ *   - 5 <= nm <= 40 (EMS_MAX_NM; reference: allocates by nbMax with no cap, init.c:310-328; start.sh runs 30); nm <= GF;
+ *   - a check node must not list one variable node twice (the reference would update that APP row twice in a row, NB_LDPC.c:444-450; none of
+ *     its matrices does);
+ *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), regular check degree <= 16, variable degree 2 (v2.c:2157 handles nothing else). */
 int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *prm, int max_batch, int device);
 void ems_destroy(ems_handle *h);
 int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */
