@@ -68,7 +68,8 @@ int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
  *   - field order GF(16), GF(64), GF(256): the reference's own list (init.c:431-435);
  *   - check degree 2..64, regular or irregular (reference: scratch sized by rowDegree[0], no cap, init.c:320; its matrices go up to 20);
  *     degrees above 16 walk the edges of a visit in passes (k_decode_wide), LDS permitting: (4 dc - 6) lists of nm + 2 entries per check node;
- *   - 5 <= nm <= 40 (EMS_MAX_NM; reference: allocates by nbMax with no cap, init.c:310-328; start.sh runs 30); nm <= GF;
+ *   - 5 <= nm <= 64 (EMS_MAX_NM; reference: allocates by nbMax with no cap, init.c:310-328; start.sh runs 30); nm <= GF;
+ *     above 32 the literal selection and bubble loop run;
  *   - a check node must not list one variable node twice (the reference would update that APP row twice in a row, NB_LDPC.c:444-450; none of
  *     its matrices does);
  *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), regular check degree <= 16, variable degree 2 (v2.c:2157 handles nothing else). */

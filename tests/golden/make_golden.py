@@ -71,6 +71,8 @@ def kat_traces():
         # messages longer than the 32 entries the fast forms hold (the reference caps nm nowhere; start.sh runs 30)
         "N40": ("ubs", "N96_K48_GF64", 150, 10, 2.0, 40, 0.3, 60),
         "N36": ("ubs", "LOCAL/Irr345_N60_M24_GF256", 60, 8, 3.0, 36, 0.3, 72),
+        "N64": ("ubs", "N96_K48_GF64", 120, 10, 2.0, 64, 0.3, 128),          # nm = GF: the whole row, NbOper beyond the 64 steps of the merge form
+        "N56": ("kn", "KN/N128_K64_GF256.txt", 80, 8, 2.5, 56, 0.3, 70),
         # check degrees above 16 (the reference sizes its scratch by rowDegree[0] with no cap, init.c:320; bubble_decoder.c:166-227 loops over
         # any dc): the rate-9/10 GF(256) matrix has dc = 20; dc = 10 is the rate-4/5 one (the dc 9..16 path was tested at dc = 12 only)
         "D20": ("ubs", "Ahmed_64800_R910_GF256", 3, 30, 3.7, 20, 0.3, 40),

@@ -59,6 +59,6 @@ def test_reference_main_on_the_gpu_library_prints_the_reference_traces(kat, tmp_
     if not os.path.exists(ESSAI_GPU):
         pytest.skip("oracle/_ref/essai_gpu is not built (make -C oracle ref, needs /root/reference)")
     k = kat[name]
-    matrix = {"N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])     # (the library's loader detects the layout itself)
+    matrix = ("KN_" + k["matrix"]) if k.get("fmt") == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]     # (the library's loader detects the layout itself)
     tr = _run(ESSAI_GPU, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]], str(tmp_path))
     assert tr == [list(t) for t in k["trace"]]

@@ -188,6 +188,9 @@ def test_decode_messages_longer_than_32_entries_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 33, 66, 0.5, 6, 1.0, 8, early_exit=False)
     _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 40, 80, 0.3, 8, 2.5, 12)
     _decode_vs_oracle(pkg, orc, "Irr345_N60_M24_GF256", 36, 72, 0.3, 8, 3.0, 8)
+    _decode_vs_oracle(pkg, orc, "N96_K48_GF64", 64, 128, 0.3, 10, 2.0, 16)                        # nm = GF (EMS_MAX_NM = 64 since round 4)
+    _decode_vs_oracle(pkg, orc, "KN_N128_K64_GF256.txt", 56, 70, 0.3, 8, 2.5, 8)
+    _decode_vs_oracle(pkg, orc, "Wide_N80_M8_GF256", 48, 96, 0.5, 5, 4.0, 4)                      # ... with check degrees above 16
 
 
 def test_decode_generic_kernels_other_degrees(pkg, orc):
@@ -305,7 +308,7 @@ def test_set_params_switches_kernels_and_keeps_the_record_layout(pkg, orc, monke
 def test_unsupported_configurations_fail_loudly(pkg):
     code = pkg.Code(os.path.join(MAT, "Mat212_N96_M16"))
     with pytest.raises(pkg.EmsError) as e:
-        pkg.Decoder(code, 41, 60, 0.3, 10, max_batch=1)          # nm > 40 (EMS_MAX_NM)
+        pkg.Decoder(code, 65, 80, 0.3, 10, max_batch=1)          # nm > 64 (EMS_MAX_NM)
     assert e.value.code == pkg.EMS_EINVAL
 
 
@@ -694,12 +697,12 @@ def _run_ems_sim(pkg, args, batch, cwd):
     return tr
 
 
-@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8),
+@pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8), ("N64", 24), ("N56", 16),
                                         ("D20", 3), ("D20b", 2), ("D10", 3), ("D10b", 3), ("W1", 64), ("W2", 50), ("W3", 33)])
 def test_c_harness_reproduces_reference_traces(pkg, kat, tmp_path, name, batch):
     """The C Monte-Carlo harness (same argv as the reference) on the GPU prints the reference's trace."""
     k = kat[name]
-    matrix = {"KN/N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    matrix = ("KN_" + k["matrix"]) if k["fmt"] == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]
     if name in ("K1", "K2"):
         matrix = "KN_N96_K48_GF64.txt"
     tr = _run_ems_sim(pkg, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]],

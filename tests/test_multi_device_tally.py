@@ -63,7 +63,7 @@ def test_c_harness_multi_device_path_with_rccl_on_one_gpu(pkg, kat, tmp_path, ca
     """EMS_DEVICES=0: ncclCommInitAll over one device, the per-round ncclAllReduce, the ordered tally -- against the traces of the
     real reference executable (K2 / K3: tests/golden/kat_traces.json; L4: 969 full-size frames to the 40th erroneous one)."""
     k = kat[case] if case in kat else json.load(open(os.path.join(GOLD, "kat_long.json")))[case]
-    matrix = {"N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    matrix = ("KN_" + k["matrix"]) if k.get("fmt") == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]
     os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
     out = subprocess.run([pkg.SIM_PATH] + [str(a) for a in (k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"])],
                          cwd=str(tmp_path), env=dict(os.environ, EMS_DEVICES="0", EMS_BATCH=str(batch)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)

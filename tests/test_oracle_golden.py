@@ -124,11 +124,11 @@ def test_trajectory_big_codes(orc, tag, mat, nm, nop):
     assert (res["sweep_crc"] == g[tag + "_crc"]).all() and (res["sweep_decide"] == g[tag + "_dec"]).all()
 
 
-@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5", "I1", "I2", "N40", "N36", "D20", "D20b", "D10", "D10b", "W1", "W2", "W3"])
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5", "I1", "I2", "N40", "N36", "N64", "N56", "D20", "D20b", "D10", "D10b", "W1", "W2", "W3"])
 def test_kat_traces(orc, kat, name):
     """End-to-end FER/BER/avr_it traces printed by the reference executable."""
     k = kat[name]
-    matrix = {"KN/N96_K48_GF64.txt": "KN_N96_K48_GF64.txt"}.get(k["matrix"], k["matrix"])
+    matrix = ("KN_" + k["matrix"]) if k["fmt"] == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]
     if name in ("K1", "K2"):
         matrix = "KN_N96_K48_GF64.txt"
     o = orc.Oracle(os.path.join(MAT, matrix))
