@@ -224,6 +224,7 @@ struct ems_handle {
                                         // (their shared APP rows are then re-read while still in L2: an experiment, see profiles/NOTES.md)
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
+    bool q16t_overlap = false;          // EMS_Q16T_OVERLAP=1 (create time): no barrier between the sweeps of a fixed-work run of that kernel
     bool wide_dc9 = false;              // EMS_WIDE=1 (create time): GF(256) codes with check degree 9..16 on k_decode_wide
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
@@ -411,7 +412,7 @@ int refresh_plan(ems_handle *h)
     P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
     P.t_cn = h->d_t_cnp.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
     P.n_pairs = h->n_pairs; P.dual = 0;
-    P.q16t = 0; P.n_groups = h->n_groups;
+    P.q16t = 0; P.n_groups = h->n_groups; P.q16t_overlap = h->q16t_overlap ? 1 : 0;
     P.q_cn = h->d_g_cn.p; P.q_vn = h->d_g_vn.p; P.q_lh = h->d_g_lh.p; P.q_pred = h->d_g_pred.p;
     P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
@@ -693,6 +694,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
         h->wide_dc9 = env_int("EMS_WIDE", 0) != 0;
+        h->q16t_overlap = env_int("EMS_Q16T_OVERLAP", 0) != 0;
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
     h->i2b.resize(256); h->b2i.resize(256);

@@ -77,6 +77,7 @@ struct EmsPlan {
     // GF(16) / dc = 8 / nm = 8 in lane-serial form (k_decode_q16t): the check nodes in GROUPS of up to 16 mutually independent ones, group i
     // depending only on groups < i
     int q16t, n_groups;     // q16t: launch k_decode_q16t
+    int q16t_overlap;       // its opt-in barrier-free form of a fixed-work run (EMS_Q16T_OVERLAP=1): Syndrom only after the last sweep
     const int *q_cn;        // [n_groups*16]  check node of slot s, or -1
     const int *q_vn;        // [n_groups*128] variable node of edge (slot * 8 + t); 0 for an empty slot
     const int *q_lh;        // [n_groups*128] log of its coefficient (0..14)
