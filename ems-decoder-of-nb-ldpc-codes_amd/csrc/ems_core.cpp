@@ -891,7 +891,10 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     // GF(16) / dc 8 / nm 8 (BASELINE configs[2]): the lane-serial kernel at every batch size, twelve waves per frame (LDS: 12.1 KiB per wave);
     // tuning.dual = 0 falls back to the one-visit kernel, > 0 (above) forces the two-visit one
     if (allow_dual && !no_dual && h->q16t_ok && ems_has_q16t_kernel(P)) {
-        int waves = h->q16t_waves > 0 ? std::min(h->q16t_waves, ems_q16t_max_waves()) : ems_q16t_max_waves();
+        // twelve waves for the one frame of a CU; from three frames per CU on, 4-wave workgroups, three to a CU (measured, fixed work, frames/s at
+        // batch 256 / 512 / 768 / 1536: 11.05e3 / 11.05e3 / -- / -- on 12 waves, -- / 9.6e3 / -- / -- on 6, -- / -- / 11.5e3 / 11.8e3 on 4)
+        const long fpc_q = h->n_cu > 0 ? ((long)B + h->n_cu - 1) / h->n_cu : 1;
+        int waves = h->q16t_waves > 0 ? std::min(h->q16t_waves, ems_q16t_max_waves()) : (fpc_q >= 3 ? 4 : ems_q16t_max_waves());
         while (waves > 1 && ems_q16t_wg_lds_bytes(P.n_groups, waves) > lds_cap) --waves;
         P.q16t = 1; P.waves_per_wg = waves;
         return;
