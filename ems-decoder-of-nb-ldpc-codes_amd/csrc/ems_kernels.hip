@@ -214,17 +214,17 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
     if (spec && P.q == 256 && P.dc == 8 && P.nm == 20) return launch_decode_t<256, 8, 8, 20>(P, B, st);   // the rate-3/4 GF(256) matrices of the reference
     if (spec && P.q == 256 && P.dc == 12 && P.nm == 20) return launch_decode_t<256, 4, 12, 20>(P, B, st);  // ... and the rate-5/6 one
     if (lpe == 16) {
-        if (P.q == 256) return launch_decode_t<256, 16>(P, B, st);
-        if (P.q == 64) return launch_decode_t<64, 16>(P, B, st);
-        if (P.q == 16) return launch_decode_t<16, 16>(P, B, st);
+        if (P.q == 256) return P.nm > 40 ? launch_decode_t<256, 16, 0, -1>(P, B, st) : launch_decode_t<256, 16>(P, B, st);
+        if (P.q == 64) return P.nm > 40 ? launch_decode_t<64, 16, 0, -1>(P, B, st) : launch_decode_t<64, 16>(P, B, st);
+        if (P.q == 16) return P.nm > 40 ? launch_decode_t<16, 16, 0, -1>(P, B, st) : launch_decode_t<16, 16>(P, B, st);
     } else if (lpe == 8) {
-        if (P.q == 256) return launch_decode_t<256, 8>(P, B, st);
-        if (P.q == 64) return launch_decode_t<64, 8>(P, B, st);
-        if (P.q == 16) return launch_decode_t<16, 8>(P, B, st);
+        if (P.q == 256) return P.nm > 40 ? launch_decode_t<256, 8, 0, -1>(P, B, st) : launch_decode_t<256, 8>(P, B, st);
+        if (P.q == 64) return P.nm > 40 ? launch_decode_t<64, 8, 0, -1>(P, B, st) : launch_decode_t<64, 8>(P, B, st);
+        if (P.q == 16) return P.nm > 40 ? launch_decode_t<16, 8, 0, -1>(P, B, st) : launch_decode_t<16, 8>(P, B, st);
     } else if (lpe == 4) {
-        if (P.q == 256) return launch_decode_t<256, 4>(P, B, st);   // 64 symbols per lane: correct, register-bound (spills)
-        if (P.q == 64) return launch_decode_t<64, 4>(P, B, st);
-        if (P.q == 16) return launch_decode_t<16, 4>(P, B, st);
+        if (P.q == 256) return P.nm > 40 ? launch_decode_t<256, 4, 0, -1>(P, B, st) : launch_decode_t<256, 4>(P, B, st);   // 64 symbols per lane: correct, register-bound (spills)
+        if (P.q == 64) return P.nm > 40 ? launch_decode_t<64, 4, 0, -1>(P, B, st) : launch_decode_t<64, 4>(P, B, st);
+        if (P.q == 16) return P.nm > 40 ? launch_decode_t<16, 4, 0, -1>(P, B, st) : launch_decode_t<16, 4>(P, B, st);
     }
     return hipErrorInvalidValue;
 }
