@@ -46,12 +46,24 @@ __device__ unsigned long long g_dbg[8];
 #else
 #define DBG_ADD(i, v) do { } while (0)
 #endif
+#elif defined(EMS_MARKS)     // listing aid (hipcc -S -DEMS_MARKS; scripts/asm_marks.py): the phase boundaries as comments in the ISA
+#define STAMP(i) asm volatile("; Q16T_MARK phase" #i)
+#define DBG_ADD(i, v) do { } while (0)
+#define ST_PARAMS
+#define ST_ARGS
+#define ST_DUMMY
 #else
 #define STAMP(i) do { } while (0)
 #define DBG_ADD(i, v) do { } while (0)
 #define ST_PARAMS
 #define ST_ARGS
 #define ST_DUMMY
+#endif
+
+#ifdef EMS_MARKS
+#define EMS_MARK(x) asm volatile("; Q16T_MARK " #x)
+#else
+#define EMS_MARK(x) do { } while (0)
 #endif
 
 #include "kernels/ems_lanes.inc"

@@ -40,4 +40,6 @@ for w in (sys.argv[1:] or ["gf256"]):
     print("  cycles per wave (waves 0-8 avg): %.3e ; => clock ~ %.2f GHz if the kernel took %.1f ms" % (per_wave_cycles, per_wave_cycles / (ms * 1e-3) / 1e9, ms))
     d = st[16:24].astype(np.float64)
     print("  selections(wave) %d, threshold iterations/selection %.2f, slow-path fraction %.4f; ES stages %d, continuation fraction %.4f, tie-fallback fraction %.4f, long-continuation fraction %.4f" % (d[0], d[1] / max(d[0], 1), d[2] / max(d[0], 1), d[3], d[4] / max(d[3], 1), d[5] / max(d[3], 1), d[6] / max(d[3], 1)))
+    a = int(st[23])
+    if a: print("  sorting-network selections %d, out-of-range fraction %.4f, near-tie fraction %.4f" % (a & 0x1FFFFF, ((a >> 21) & 0x1FFFFF) / max(a & 0x1FFFFF, 1), (a >> 42) / max(a & 0x1FFFFF, 1)))
     dec.close()

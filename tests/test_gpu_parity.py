@@ -433,6 +433,44 @@ def test_saturated_and_negative_llrs(pkg, orc):
     dec.close()
 
 
+def test_gf64_network_selection_edge_inputs(pkg, orc, monkeypatch):
+    """GF(64) / nm = 16 on the two-visit and two-frame kernels, whose top-16 selection is a sorting network over 32-bit keys (value bits
+    with the symbol in the low six): rows it must hand to the threshold / literal selection -- values within 64 ulp of each other
+    around the 16th place and inside the top 16, exact ties, negative values, values >= 1e5, fewer than nm selectable symbols --
+    next to continuous rows it decides alone.  Whole-frame state against the oracle."""
+    path = os.path.join(MAT, "N96_K48_GF64")
+    o = orc.Oracle(path)
+    rs = np.random.RandomState(23)
+    llr = (rs.rand(8, o.N, o.q) * 40).astype(np.float32)
+    one = np.float32(5.0)
+    ulp = np.spacing(one)
+    llr[0, :, :24] = one + ulp * rs.randint(0, 200, size=(o.N, 24)).astype(np.float32)    # a cluster a few ulp wide holds the whole top 16
+    llr[1, :, 10:20] = llr[1, :, 10:11] + ulp * np.arange(10, dtype=np.float32)          # ten values one ulp apart, somewhere in the order
+    srt = np.sort(llr[2], axis=1)
+    llr[2] = np.where(llr[2] == srt[:, 16:17], srt[:, 15:16] + np.spacing(srt[:, 15:16]), llr[2])   # the 17th one ulp above the 16th
+    llr[3] = np.round(llr[3])                                                            # exact ties
+    llr[4] -= 15.0                                                                       # negative entries
+    llr[5, :, 20:] = 1e5                                                                 # fewer than nm selectable symbols
+    llr[5, 3, :] = 2e5                                                                   # ... and a node with none
+    llr[6, ::3] = np.round(llr[6, ::3] * 4) / 4                                          # every third node on a grid, the rest continuous
+    # (frame 7: continuous)
+    refs = [o.decode(llr[b], 16, 32, 0.3, 6, want_state=True) for b in range(8)]
+    for knob, val in (("EMS_DUAL", "1"), ("EMS_DUAL", "2"), ("EMS_TWIN", "1")):
+        monkeypatch.setenv(knob, val)
+        dec = pkg.Decoder(pkg.Code(path), 16, 32, 0.3, 6, max_batch=8)
+        dec.load_llr(llr)
+        dec.decode(8)
+        d, it, sy = dec.results(8)
+        assert ("dual" in dec.last_kernel or "twin" in dec.last_kernel), dec.last_kernel
+        for b in range(8):
+            ref = refs[b]
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], (knob, val, b)
+            assert dec.app(b).tobytes() == ref["app"].tobytes(), (knob, val, b)
+            assert dec.ctov(b).tobytes() == ref["ctov"].tobytes(), (knob, val, b)
+        dec.close()
+        monkeypatch.delenv(knob)
+
+
 def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
     """GF(16) / nm = 8 on the two-visits-per-wave kernel with LLRs on a coarse grid: equal first occurrences in nearly every elementary
     step, i.e. the stage leaves the first-occurrence loop and the rest of the visit runs in the merge form through the out-of-line
