@@ -121,8 +121,11 @@ int build_cn_schedule(int dc, CnSchedule &s)
 // order, NB_LDPC.c:320) that share a variable node with c.  Check nodes inside a level touch disjoint
 // APP rows, and CtoV rows are private to their check node (NB_LDPC.c:438), so visiting the levels in
 // order -- in any order inside a level -- is the sequential sweep exactly.
-int level_schedule(const ems_code_desc *c, std::vector<int> &lvl_ptr, std::vector<int> &lvl_cn)
+// A check node may list one variable node twice (two edges, two coefficients; none of the reference's matrices does, nothing in it forbids it):
+// *repeats, when given, receives the number of such edges.
+int level_schedule(const ems_code_desc *c, std::vector<int> &lvl_ptr, std::vector<int> &lvl_cn, long *repeats = nullptr)
 {
+    long nrep = 0;
     std::vector<int> vn_level(c->N, -1), level(c->M, 0);
     int nlev = 0;
     long e0 = 0;
@@ -133,7 +136,7 @@ int level_schedule(const ems_code_desc *c, std::vector<int> &lvl_ptr, std::vecto
             const int v = c->col[e0 + i], cf = c->coef[e0 + i];
             if (v < 0 || v >= c->N || cf < 1 || cf >= c->GF) return fail(EMS_EINVAL, "edge %ld out of range", e0 + i);
             for (int j = 0; j < i; ++j)
-                if (c->col[e0 + j] == v) return fail(EMS_EUNSUPPORTED, "check node %d lists variable node %d twice", m, v);
+                if (c->col[e0 + j] == v) { ++nrep; break; }
             lv = std::max(lv, vn_level[v] + 1);
         }
         level[m] = lv;
@@ -147,6 +150,7 @@ int level_schedule(const ems_code_desc *c, std::vector<int> &lvl_ptr, std::vecto
     lvl_cn.resize(c->M);
     std::vector<int> fill(lvl_ptr.begin(), lvl_ptr.end() - 1);
     for (int m = 0; m < c->M; ++m) lvl_cn[fill[level[m]]++] = m;
+    if (repeats) *repeats = nrep;
     return EMS_OK;
 }
 
@@ -182,7 +186,8 @@ struct ems_handle {
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
     bool wide = false;                   // largest check degree above 16: k_decode_wide
-    bool regular = true;                 // every check node has degree dc; else dc = the largest degree and the tables below are used
+    bool regular = true;                 // every check node has degree dc (and no check node lists a variable node twice); else dc = the largest degree and the tables below are used
+    long repeats = 0;                    // edges that repeat a variable node of their own check node
     std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
     DevBuf<int> d_row_ptr, d_t_dc, d_t_e0;
     std::vector<int> p_cn, p_vn, p_lh, p_pred, p_task;   // check nodes in pairs (k_decode_dual), see build_pairs; p_task: task index per (pair, member), -1 = none
@@ -470,12 +475,11 @@ void build_tasks(ems_handle *h, const ems_code_desc *c)
         std::vector<int> pred_cn((size_t)E, -1);
         std::vector<long> rp(h->M + 1, 0);                         // first edge of each check node
         for (int m = 0; m < h->M; ++m) rp[m + 1] = rp[m] + c->rowDegree[m];
-        for (int m = 0; m < h->M; ++m)
-            for (int i = 0; i < c->rowDegree[m]; ++i) {
-                const int v = c->col[rp[m] + i];
-                pred_cn[(size_t)rp[m] + i] = last_cn[v];
-                last_cn[v] = m;
-            }
+        for (int m = 0; m < h->M; ++m) {                           // (two passes per check node: an edge that repeats a variable node of its own
+            for (int i = 0; i < c->rowDegree[m]; ++i)              //  check waits for the same earlier visitor as the first one)
+                pred_cn[(size_t)rp[m] + i] = last_cn[c->col[rp[m] + i]];
+            for (int i = 0; i < c->rowDegree[m]; ++i) last_cn[c->col[rp[m] + i]] = m;
+        }
         // per (task, edge row) tables with the stride of the largest degree; the rows a shorter check node leaves over repeat its
         // last edge (they shadow it, their stores are masked) and wait for nothing
         const size_t T = (size_t)h->M * h->dc;
@@ -488,6 +492,10 @@ void build_tasks(ems_handle *h, const ems_code_desc *c)
                 const size_t e = (size_t)rp[m] + std::min(k, dm - 1);
                 h->t_vn[(size_t)i * h->dc + k] = c->col[e];
                 h->t_lh[(size_t)i * h->dc + k] = c->coef[e] - 1;
+                // a LATER edge of this check node names the same variable node: the reference updates the APP row once per edge in edge order
+                // (NB_LDPC.c:444-450), so that later update is the one that stays -- this row keeps its APP row and its decision to itself
+                for (int k2 = k + 1; k2 < dm; ++k2)
+                    if (k < dm && c->col[rp[m] + k2] == c->col[e]) { h->t_lh[(size_t)i * h->dc + k] |= EMS_LH_NOAPP; break; }
                 h->t_pred[(size_t)i * h->dc + k] = (k >= dm || pred_cn[e] < 0) ? -1 : task_of[pred_cn[e]];
             }
         }
@@ -732,7 +740,10 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     h->cn_vn.assign(c->col, c->col + E);
     h->cn_lh.resize(E);
     for (long e = 0; e < E; ++e) h->cn_lh[e] = (uint8_t)(c->coef[e] - 1);
-    if ((r = level_schedule(c, h->lvl_ptr, h->lvl_cn))) return bail(r);
+    if ((r = level_schedule(c, h->lvl_ptr, h->lvl_cn, &h->repeats))) return bail(r);
+    // a check node that lists a variable node twice: the generic one-visit kernels (per-row "keeps its APP row to itself" flag in t_lh), as
+    // for irregular degrees
+    if (h->repeats) h->regular = false;
     {   // Hard decisions are written by the check-node visits; a variable node outside every check (column degree 0)
         // keeps its channel APP for the whole decode, so Decision (tools.c:312) gives the same symbol every sweep: it is
         // decided once, right after the LLR init (k_decide_rows).
@@ -1128,6 +1139,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
 static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
+    if (h->repeats) return fail(EMS_EUNSUPPORTED, "v2 flavour: a check node lists a variable node twice (v2.c:2157 pairs the two edges of a variable node across check nodes)");
     if (!h->regular) return fail(EMS_EUNSUPPORTED, "v2 flavour: irregular check degrees are not built");
     if (!ems_lpe_for(h->dc)) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 16 is not built", h->dc);
     if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
@@ -1372,8 +1384,9 @@ int ems_pair_schedule(const ems_code_desc *code, int *n_pairs, int *pair_cn)
     for (int m = 0; m < code->M; ++m)
         if (code->rowDegree[m] != hh.dc) return fail(EMS_EUNSUPPORTED, "irregular check degree");
     if (hh.dc != 4 && hh.dc != 8) return fail(EMS_EUNSUPPORTED, "pairs are built for check degree 4 and 8 (the two-visits-per-wave kernels)");
-    int r = level_schedule(code, hh.lvl_ptr, hh.lvl_cn);
+    int r = level_schedule(code, hh.lvl_ptr, hh.lvl_cn, &hh.repeats);
     if (r) return r;
+    if (hh.repeats) return fail(EMS_EUNSUPPORTED, "a check node lists a variable node twice: no pairs (the generic kernels run such codes)");
     build_tasks(&hh, code);
     build_pairs(&hh);
     *n_pairs = hh.n_pairs;
@@ -1470,6 +1483,13 @@ int ems_suggest_batch(const ems_code_desc *c, const ems_params *prm, int device,
     for (int m = 0; m < c->M; ++m) {
         dc = std::max(dc, c->rowDegree[m]);
         regular = regular && c->rowDegree[m] == c->rowDegree[0];
+    }
+    {   // (a check node that lists a variable node twice: generic kernels too)
+        long e0 = 0;
+        for (int m = 0; m < c->M && regular; e0 += c->rowDegree[m], ++m)
+            for (int i = 1; i < c->rowDegree[m] && regular; ++i)
+                for (int j = 0; j < i; ++j)
+                    if (c->col[e0 + j] == c->col[e0 + i]) { regular = false; break; }
     }
     const int q = c->GF, logq = ilog2(q);
     const bool generic_only = !regular || dc > 16;

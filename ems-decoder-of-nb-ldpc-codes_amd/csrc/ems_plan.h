@@ -15,6 +15,7 @@ struct EmsEntry {
 #define EMS_SENTINEL 1e5f
 #define EMS_S_INVALID 0x100u
 #define EMS_S_BOUND 0x200u
+#define EMS_LH_NOAPP 0x10000   // t_lh: this edge row keeps its APP row and decision to itself (a later edge of the check node names the same variable node)
 #define EMS_MAX_NM 64      // messages longer than this are not built (reference usage: 8..30; 40 until round 4); above EMS_FAST_NM the literal forms run
 #define EMS_FAST_NM 32     // the merge form of the elementary step records a list position in 5 bits, the selection keeps 32 survivors
 #define EMS_MAX_STEPS 14   // dc-2 forward/backward steps of the kernels that keep a stage table (dc <= 16)

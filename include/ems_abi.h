@@ -70,9 +70,10 @@ int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
  *     degrees above 16 walk the edges of a visit in passes (k_decode_wide), LDS permitting: (4 dc - 6) lists of nm + 2 entries per check node;
  *   - 5 <= nm <= 64 (EMS_MAX_NM; reference: allocates by nbMax with no cap, init.c:310-328; start.sh runs 30); nm <= GF;
  *     above 32 the literal selection and bubble loop run;
- *   - a check node must not list one variable node twice (the reference would update that APP row twice in a row, NB_LDPC.c:444-450; none of
- *     its matrices does);
- *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), regular check degree <= 16, variable degree 2 (v2.c:2157 handles nothing else). */
+ *   - a check node may list one variable node twice (none of the reference's matrices does; nothing in it forbids it): both edges read the
+ *     same APP row (NB_LDPC.c:329-337), the later edge's APP update and decision stay (:444-450); such codes run the generic kernels;
+ *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), regular check degree <= 16, variable degree 2 on two different check nodes (v2.c:2157
+ *     handles nothing else). */
 int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *prm, int max_batch, int device);
 void ems_destroy(ems_handle *h);
 int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */

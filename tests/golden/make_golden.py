@@ -84,6 +84,12 @@ def kat_traces():
         "W1": ("ubs", "LOCAL/Wide_N80_M8_GF64", 200, 10, 4.5, 16, 0.3, 32),
         "W2": ("ubs", "LOCAL/Wide_N80_M8_GF256", 150, 12, 4.5, 20, 0.3, 40),
         "W3": ("ubs", "LOCAL/Wide_N120_M6_GF16", 150, 10, 5.0, 8, 0.3, 16),
+        # check nodes that list one variable node twice (make_repeat_matrix.py): both edges read the same APP row, the later edge's update stays
+        # (NB_LDPC.c:329-337, :444-450).  The reference's encoder keeps one coefficient per (row, column), so its codewords do not satisfy these
+        # checks and no frame converges -- the bit-error counts after 10 sweeps are the behaviour pinned here
+        "R1": ("ubs", "LOCAL/Rep_N40_M20_GF64", 60, 10, 3.0, 12, 0.3, 24),
+        "R2": ("ubs", "LOCAL/Rep_N40_M20_GF64", 40, 6, 6.0, 16, 0.5, 32),
+        "R3": ("ubs", "LOCAL/RepWide_N54_M6_GF64", 60, 8, 5.0, 16, 0.3, 32),     # check degree 18: repeats inside and across the passes of k_decode_wide
     }
     dst = os.path.join(HERE, "kat_traces.json")
     out = json.load(open(dst)) if os.path.exists(dst) and os.environ.get("KAT_KEEP", "1") == "1" else {}

@@ -52,7 +52,7 @@ def _run(exe, args, cwd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K4", "K5", "I1", "N40", "N64", "D20b", "D10", "W2"])
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K4", "K5", "I1", "N40", "N64", "D20b", "D10", "W2", "R1", "R3"])
 def test_reference_main_on_the_gpu_library_prints_the_reference_traces(kat, tmp_path, name):
     """NB_LDPC.c's own main() -- argv parsing, LoadCode ... ModelChannel_AWGN_BPSK, BER/FER counting, progress line, 40-error stop --
     driving libems_hip.so through Decoding(): the trace of the unmodified reference executable, frame for frame."""

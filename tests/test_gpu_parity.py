@@ -243,6 +243,19 @@ def test_decode_check_degrees_above_16_vs_oracle(pkg, orc):
     _decode_vs_oracle(pkg, orc, "Wide_N120_M6_GF16", 12, 24, 0.5, 8, 4.0, 8, early_exit=False)
 
 
+def test_decode_repeated_variable_nodes_vs_oracle(pkg, orc):
+    """Check nodes that list one variable node twice (tests/golden/make_repeat_matrix.py; kat_traces.json R1..R3 are the REAL executable's
+    traces): both edges read the same APP row (NB_LDPC.c:329-337), the later edge's APP update and decision stay (:444-450).  The generic
+    one-visit kernel (dc = 4) and k_decode_wide (dc = 18: repeats inside a pass and across the two), whole-frame state against the oracle,
+    fast and literal forms, early exit on and off."""
+    it = _decode_vs_oracle(pkg, orc, "Rep_N40_M20_GF64", 12, 24, 0.3, 10, 3.0, 24)
+    _decode_vs_oracle(pkg, orc, "Rep_N40_M20_GF64", 16, 32, 0.5, 6, 6.0, 16, early_exit=False)
+    _decode_vs_oracle(pkg, orc, "Rep_N40_M20_GF64", 40, 60, 0.3, 5, 4.0, 4)                          # literal forms (nm > 32)
+    _decode_vs_oracle(pkg, orc, "RepWide_N54_M6_GF64", 16, 32, 0.3, 8, 5.0, 24)
+    _decode_vs_oracle(pkg, orc, "RepWide_N54_M6_GF64", 12, 15, 1.0, 6, 3.0, 5, early_exit=False)
+    assert it is not None
+
+
 def test_decode_gf256_dc20_vs_oracle(pkg, orc):
     """The reference's rate-9/10 GF(256) matrix (Ahmed_64800_R910_GF256, dc = 20; kat_traces.json D20 / D20b from the real executable):
     a frame that converges and one that does not, whole state."""
@@ -736,7 +749,7 @@ def _run_ems_sim(pkg, args, batch, cwd):
 
 
 @pytest.mark.parametrize("name,batch", [("K1", 5), ("K1_ubs", 64), ("K2", 64), ("K3", 4), ("K4", 4), ("K5", 128), ("I1", 16), ("I2", 7), ("N40", 32), ("N36", 8), ("N64", 24), ("N56", 16),
-                                        ("D20", 3), ("D20b", 2), ("D10", 3), ("D10b", 3), ("W1", 64), ("W2", 50), ("W3", 33)])
+                                        ("D20", 3), ("D20b", 2), ("D10", 3), ("D10b", 3), ("W1", 64), ("W2", 50), ("W3", 33), ("R1", 16), ("R2", 7), ("R3", 32)])
 def test_c_harness_reproduces_reference_traces(pkg, kat, tmp_path, name, batch):
     """The C Monte-Carlo harness (same argv as the reference) on the GPU prints the reference's trace."""
     k = kat[name]

@@ -124,7 +124,7 @@ def test_trajectory_big_codes(orc, tag, mat, nm, nop):
     assert (res["sweep_crc"] == g[tag + "_crc"]).all() and (res["sweep_decide"] == g[tag + "_dec"]).all()
 
 
-@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5", "I1", "I2", "N40", "N36", "N64", "N56", "D20", "D20b", "D10", "D10b", "W1", "W2", "W3"])
+@pytest.mark.parametrize("name", ["K1", "K1_ubs", "K2", "K3", "K3b", "K4", "K5", "I1", "I2", "N40", "N36", "N64", "N56", "D20", "D20b", "D10", "D10b", "W1", "W2", "W3", "R1", "R2", "R3"])
 def test_kat_traces(orc, kat, name):
     """End-to-end FER/BER/avr_it traces printed by the reference executable."""
     k = kat[name]
