@@ -1,0 +1,153 @@
+"""Seeded random codes through the library against the oracle, whole-frame state: check degrees from 2 to 40 (regular and mixed, the largest
+in row 0 as the reference's scratch sizing wants it, init.c:320), GF(16) / GF(64) / GF(256), variable nodes of any degree including 0
+(never visited: decided once from the channel) and check nodes that list a variable node twice, random nm / NbOper / offset / NbIterMax,
+early exit on and off, LLR rows that are continuous, on a grid (ties) or partly saturated.  The matrices are written in the reference's
+block alist layout (init.c:195-207) into a temporary directory; the decode input is the LLR block itself (no encoder in the loop), so a
+rank-deficient random matrix is as good as any.  Every kernel family the shape policy can pick for such codes is exercised: the generic
+one-visit kernels (rows of 16 / 8 / 4 lanes), k_decode_wide, the (dc, nm)-specialised ones when a regular code happens to fit them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from make_irregular_matrix import write  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+DEGREE_SETS = [[2], [3], [4], [2, 3], [3, 4, 5], [5, 6, 7, 8], [8], [9, 10, 12], [13, 16], [17, 18, 20], [24, 19, 17], [2, 9, 17], [33, 20, 40]]
+
+
+def _random_code(rs, path):
+    q = int(rs.choice([16, 64, 256]))
+    degs = DEGREE_SETS[int(rs.randint(len(DEGREE_SETS)))]
+    M = int(rs.randint(3, 9))
+    deg = sorted((int(rs.choice(degs)) for _ in range(M)), reverse=True)            # the largest degree in row 0
+    E = sum(deg)
+    N = int(max(max(deg) + 1, M + 1, E // int(rs.choice([1, 2, 3]))))                  # average column degree about 1, 2 or 3 (and K = N - M > 0)
+    N += int(rs.randint(0, 3))                                                         # ... and now and then a variable node in no check
+    rows = []
+    for d in deg:
+        r = [int(c) for c in rs.choice(N, d, replace=False)]
+        if d >= 3 and rs.rand() < 0.25:                                                # a variable node listed twice
+            i, j = (int(x) for x in rs.choice(d, 2, replace=False))
+            r[j] = r[i]
+        rows.append(r)
+    coefs = [[int(x) for x in rs.randint(1, q, d)] for d in deg]
+    write(path, N, M, q, deg, rows, coefs)
+    return q, N, deg, any(len(set(r)) < len(r) for r in rows)
+
+
+@pytest.mark.parametrize("block", range(12))
+def test_random_codes_vs_oracle(pkg, orc, tmp_path, block):
+    rs = np.random.RandomState(4100 + block)
+    ran = 0
+    kernels = set()
+    for case in range(16):
+        path = str(tmp_path / ("fuzz_%d_%d" % (block, case)))
+        q, N, deg, rep = _random_code(rs, path)
+        nm = int(rs.randint(5, min(q, 40) + 1))
+        if rs.rand() < 0.15:
+            nm = min(q, int(rs.randint(41, 65)))                                       # the long-message builds
+        nop = int(rs.choice([nm, nm + 3, 2 * nm, 3 * nm, 70]))
+        off = float(rs.choice([0.0, 0.3, 1.0]))
+        itmax = int(rs.randint(2, 6))
+        ee = bool(rs.randint(2))
+        B = 3
+        llr = (rs.rand(B, N, q) * 30).astype(np.float32)
+        llr[1] = np.round(llr[1] * 2) / 2                                              # ties
+        llr[2, ::2, q // 2:] = 1e5                                                     # half the symbols of every other node not selectable
+        llr -= llr.min(axis=2, keepdims=True)                                          # the channel's normalisation: 0 at the best symbol
+        llr[2, ::2, q // 2:] = 1e5
+        o = orc.Oracle(path)
+        try:
+            dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=B, early_exit=ee)
+        except pkg.EmsError as e:                                                      # a combination the library states it does not build
+            assert e.code == pkg.EMS_EUNSUPPORTED, (deg, q, nm, str(e))
+            continue
+        dec.load_llr(llr)
+        dec.decode(B)
+        d, it, sy = dec.results(B)
+        kernels.add(dec.last_kernel.split("(")[0])
+        for b in range(B):
+            ref = o.decode(llr[b], nm, nop, off, itmax, early_exit=ee, want_state=True)
+            ctx = (block, case, q, deg, nm, nop, off, itmax, ee, rep, dec.last_kernel, b)
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], ctx
+            assert dec.app(b).tobytes() == ref["app"].tobytes(), ctx
+            assert dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
+        dec.close()
+        ran += 1
+    print("block %d: %d of 16 cases ran, kernels %s" % (block, ran, sorted(kernels)))
+    assert ran >= 10, ran                                                              # (most combinations are built)
+    assert len(kernels) >= 2, kernels
+
+
+def _random_regular_code(rs, path, q, dc):
+    """M checks of degree dc over N variable nodes, no variable node twice in a check, column degrees 1..4 (mostly 2)."""
+    M = int(rs.randint(5, 41))
+    E = M * dc
+    N = max(M + 1, dc + 1, E // 2 + int(rs.randint(-2, 3)))
+    while True:
+        slots = [int(c) for c in rs.permutation(N)] + [int(c) for c in rs.randint(0, N, max(0, E - N))]
+        slots = slots[:E]
+        rs.shuffle(slots)
+        rows = [slots[m * dc:(m + 1) * dc] for m in range(M)]
+        if all(len(set(r)) == dc for r in rows):
+            break
+    coefs = [[int(x) for x in rs.randint(1, q, dc)] for _ in range(M)]
+    write(path, N, M, q, [dc] * M, rows, coefs)
+    return N, M
+
+
+FAMILIES = [  # q, dc, nm, the knobs that force each kernel family built for this shape ({} = the library's own choice)
+    (256, 4, 20, [{}, {"EMS_DUAL": "1"}, {"EMS_DUAL": "2"}, {"EMS_DUAL": "4"}, {"EMS_TWIN": "1"}, {"EMS_WAVES": "4", "EMS_OCC4": "1"}]),
+    (64, 4, 16, [{}, {"EMS_DUAL": "1"}, {"EMS_DUAL": "2"}, {"EMS_TWIN": "1"}]),
+    (64, 4, 24, [{}, {"EMS_DUAL": "2"}]),
+    (16, 8, 8, [{}, {"EMS_Q16T": "0"}, {"EMS_DUAL": "2"}, {"EMS_Q16T_WAVES": "3"}]),
+]
+
+
+@pytest.mark.parametrize("fam", range(len(FAMILIES)))
+def test_random_regular_codes_through_the_specialised_kernels(pkg, orc, tmp_path, monkeypatch, fam):
+    """Random REGULAR graphs (their level structure, pairs and groups of 16 differ from code to code: build_pairs / build_groups and the
+    dependency flags of the persistent kernels see topologies the fixed matrices do not have) through every kernel family built for the
+    shape -- one visit per wave, two visits, two frames, the lane-serial GF(16) kernel -- whole-frame state against the oracle."""
+    q, dc, nm, knobs = FAMILIES[fam]
+    rs = np.random.RandomState(5200 + fam)
+    seen = set()
+    for case in range(14):
+        path = str(tmp_path / ("reg_%d_%d" % (fam, case)))
+        N, M = _random_regular_code(rs, path, q, dc)
+        nop = int(rs.choice([nm + 3, 2 * nm, 2 * nm, 3 * nm]))
+        off = float(rs.choice([0.0, 0.3, 1.0]))
+        itmax = int(rs.randint(2, 7))
+        ee = bool(rs.randint(2))
+        B = int(rs.randint(3, 10))
+        llr = (rs.rand(B, N, q) * 30).astype(np.float32)
+        llr[1] = np.round(llr[1] * 2) / 2
+        llr[2, ::3, q // 2:] = 1e5
+        llr -= llr.min(axis=2, keepdims=True)
+        llr[2, ::3, q // 2:] = 1e5
+        o = orc.Oracle(path)
+        refs = [o.decode(llr[b], nm, nop, off, itmax, early_exit=ee, want_state=True) for b in range(B)]
+        for kn in knobs:
+            for k, v in kn.items():
+                monkeypatch.setenv(k, v)
+            dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=B, early_exit=ee)
+            dec.load_llr(llr)
+            dec.decode(B)
+            d, it, sy = dec.results(B)
+            seen.add(dec.last_kernel.split("(")[0])
+            for b in range(B):
+                ref = refs[b]
+                ctx = (fam, case, M, N, nop, off, itmax, ee, kn, dec.last_kernel, b)
+                assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], ctx
+                assert dec.app(b).tobytes() == ref["app"].tobytes(), ctx
+                assert dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
+            dec.close()
+            for k in kn:
+                monkeypatch.delenv(k)
+    print("family", (q, dc, nm), sorted(seen))
+    assert len(seen) >= 2, seen
