@@ -151,3 +151,60 @@ def test_random_regular_codes_through_the_specialised_kernels(pkg, orc, tmp_path
                 monkeypatch.delenv(k)
     print("family", (q, dc, nm), sorted(seen))
     assert len(seen) >= 2, seen
+
+
+def _random_dv2_code(rs, path, q, dc):
+    """A random (2, dc)-regular graph: every variable node on exactly two DIFFERENT check nodes (what the v2 flavour decodes, v2.c:2157)."""
+    M = 2 * int(rs.randint(3, 25))
+    N = M * dc // 2
+    while True:
+        slots = [int(c) for c in rs.permutation(np.repeat(np.arange(N), 2))]
+        rows = [slots[m * dc:(m + 1) * dc] for m in range(M)]
+        if all(len(set(r)) == dc for r in rows):
+            break
+    coefs = [[int(x) for x in rs.randint(1, q, dc)] for _ in range(M)]
+    write(path, N, M, q, [dc] * M, rows, coefs)
+    return N, M
+
+
+@pytest.mark.parametrize("q,logq,dc,nm", [(256, 8, 4, 20), (64, 6, 4, 12), (64, 6, 3, 8), (256, 8, 6, 16), (64, 6, 8, 10), (256, 8, 12, 20)])
+def test_random_dv2_codes_through_the_v2_flavour(pkg, orc, tmp_path, monkeypatch, q, logq, dc, nm):
+    """The v2 flavour (ems_v2_*) on random (2, dc)-regular graphs -- its destination-edge tables, its last-visitor flags and the pair tables
+    of k_decode_v2_dual depend on the topology -- every message array, APP and decision against the v2 oracle."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    v2 = importlib.import_module("orc_v2")
+    rs = np.random.RandomState(6300 + q + dc)
+    seen = set()
+    for case in range(6):
+        path = str(tmp_path / ("v2_%d_%d_%d" % (q, dc, case)))
+        N, M = _random_dv2_code(rs, path, q, dc)
+        nop = int(rs.choice([nm, nm + 3, 2 * nm, 3 * nm]))
+        off = float(rs.choice([0.0, 0.3, 0.5, 1.0]))
+        itmax = int(rs.randint(2, 7))
+        ee = bool(rs.randint(2))
+        o = v2.V2Oracle(path)
+        cases = [(float(rs.choice([0.6, 0.8, 1.0, 1.3])), int(rs.randint(1, 10 ** 6))) for _ in range(3)]
+        pairs = [v2.synthetic_likelihood(o.N, q, logq, o.o.idx2bin, sg, seed) for sg, seed in cases]
+        like = np.stack([p[0] for p in pairs])
+        idx = np.stack([p[1] for p in pairs])
+        refs = [o.decode(like[b], idx[b], nm, nop, off, itmax, early_exit=ee) for b in range(3)]
+        for kn in ({}, {"EMS_DUAL": "1"}, {"EMS_DUAL": "2"}):
+            if kn and not (dc == 4 and nm == 20 and nop >= 23):
+                continue                                                               # (the two-visit v2 kernel is built for dc 4 / nm 20)
+            for k, v in kn.items():
+                monkeypatch.setenv(k, v)
+            dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=3, early_exit=ee)
+            decide, iters, synd = dec.v2_decode_batch(like, idx)
+            seen.add(dec.last_kernel.split("(")[0])
+            for b in range(3):
+                ref = refs[b]
+                ctx = (q, dc, case, M, nop, off, itmax, ee, kn, dec.last_kernel, b)
+                assert iters[b] == ref["iters"] and synd[b] == ref["synd"] and (decide[b] == ref["decide"]).all(), ctx
+                st = dec.v2_state(b)
+                for k in ("vtoc", "vtoci", "ctov", "ctovi", "app"):
+                    assert st[k].tobytes() == ref[k].tobytes(), ctx + (k,)
+            dec.close()
+            for k in kn:
+                monkeypatch.delenv(k)
+    print("v2", (q, dc, nm), sorted(seen))
