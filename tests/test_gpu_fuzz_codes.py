@@ -208,3 +208,35 @@ def test_random_dv2_codes_through_the_v2_flavour(pkg, orc, tmp_path, monkeypatch
             for k in kn:
                 monkeypatch.delenv(k)
     print("v2", (q, dc, nm), sorted(seen))
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_c_harness_on_random_codes_equals_the_oracle_simulation(pkg, orc, tmp_path, block):
+    """The C Monte-Carlo harness (the reference's argv; frame source, encoder, channel, decode on the GPU, statistics) on the seeded random
+    codes of tests/fuzz_codes.py prints the trace of the oracle's simulation -- which tests/test_oracle_fuzz_vs_reference.py holds to the REAL
+    executable on the same codes where that executable exists.  A rank-deficient matrix ends both before the first frame (tools.c:181-185)."""
+    import re
+    import subprocess
+    from fuzz_codes import simulation_case
+    ran = 0
+    for seed in range(block * 10, block * 10 + 10):
+        path = str(tmp_path / ("rnd_%d" % seed))
+        frames, it, eb, nm, off, nop = simulation_case(seed, path)
+        o = orc.Oracle(path)
+        cwd = str(tmp_path)
+        os.makedirs(os.path.join(cwd, "data"), exist_ok=True)
+        out = subprocess.run([pkg.SIM_PATH] + [str(a) for a in (frames, it, path, eb, nm, off, nop)], cwd=cwd,
+                             env=dict(os.environ, EMS_BATCH=str(3 + seed % 7)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        txt = out.stdout.decode("latin-1")
+        tr = [(int(m.group(1)), int(m.group(3)), m.group(4)) for m in
+              re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", txt)]
+        try:
+            rec = o.sim(orc.Rng(0), eb, nm, nop, off, it, frames)
+        except RuntimeError as e:
+            assert "not full rank" in str(e) and "not full rank" in txt and not tr, (seed, str(e), txt[-300:])
+            continue
+        assert out.returncode == 0, (seed, out.stderr.decode()[-1000:])
+        mine = orc.trace_from_records(rec, o.K, o.logq)
+        assert [list(t) for t in tr] == [list(t) for t in mine], (seed, nm, nop, off, it, eb)
+        ran += 1
+    assert ran >= 7, ran
