@@ -428,7 +428,7 @@ int refresh_plan(ems_handle *h)
     P.wave_lds_bytes = h->wide ? (int)ems_wide_wave_lds_bytes(h->q, h->dc, p.nm) : (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
     int widest = 1;
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-    const int wcap = h->wide ? 4 : ems_max_waves_for(h->dc, h->q);
+    const int wcap = h->wide ? 8 : ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
     if (h->tune.waves > 0) waves = std::max(1, std::min(wcap, h->tune.waves));                  // ems_set_tuning
     const size_t lds_cap = 160 * 1024;

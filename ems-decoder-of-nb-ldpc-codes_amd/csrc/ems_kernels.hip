@@ -197,7 +197,7 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
         return launch_decode_q16t(P, B, st);
     }
     if (P.wide) {
-        if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > 4 || P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm))
+        if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > 8 || P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm))
             return hipErrorInvalidValue;
         if (P.q == 256) return launch_decode_wide_t<256, 8>(P, B, st);
         if (P.q == 64) return launch_decode_wide_t<64, 4>(P, B, st);
