@@ -40,7 +40,7 @@ def _random_code(rs, path):
     return q, N, deg, any(len(set(r)) < len(r) for r in rows)
 
 
-@pytest.mark.parametrize("block", range(12))
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_BLOCKS", "12"))))      # (EMS_FUZZ_BLOCKS=300: a one-minute soak of 4800 codes)
 def test_random_codes_vs_oracle(pkg, orc, tmp_path, block):
     rs = np.random.RandomState(4100 + block)
     ran = 0
@@ -117,7 +117,7 @@ def test_random_regular_codes_through_the_specialised_kernels(pkg, orc, tmp_path
     q, dc, nm, knobs = FAMILIES[fam]
     rs = np.random.RandomState(5200 + fam)
     seen = set()
-    for case in range(14):
+    for case in range(int(os.environ.get("EMS_FUZZ_REGULAR", "14"))):
         path = str(tmp_path / ("reg_%d_%d" % (fam, case)))
         N, M = _random_regular_code(rs, path, q, dc)
         nop = int(rs.choice([nm + 3, 2 * nm, 2 * nm, 3 * nm]))
@@ -240,3 +240,69 @@ def test_c_harness_on_random_codes_equals_the_oracle_simulation(pkg, orc, tmp_pa
         assert [list(t) for t in tr] == [list(t) for t in mine], (seed, nm, nop, off, it, eb)
         ran += 1
     assert ran >= 7, ran
+
+
+@pytest.mark.parametrize("q,deg,nm,nop", [(256, [40, 40, 33, 20, 20], 52, 156), (64, [64, 50, 40, 64], 32, 64), (64, [64, 33, 64], 40, 43), (256, [64, 64, 17], 31, 62),
+                                          (16, [64, 64, 40], 16, 32)])
+def test_list_areas_beyond_64_kib(pkg, orc, tmp_path, q, deg, nm, nop):
+    """Check nodes whose message lists take more than 64 KiB of LDS (4 dc - 6 lists of nm + 2 entries: dc = 40 with nm >= 52, dc = 64 with
+    nm >= 31): the elementary-step task descriptors carried BYTE offsets in 16 bits until a seeded random code of the soak
+    (EMS_FUZZ_BLOCKS=300, block 53) found them wrapping; they carry entry offsets now.  Whole-frame state against the oracle."""
+    rs = np.random.RandomState(len(deg) * 1000 + nm)
+    N = max(deg) + 12
+    rows = [[int(c) for c in rs.choice(N, d, replace=False)] for d in deg]
+    rows[1][3] = rows[1][0]                                                            # (and a repeated variable node)
+    coefs = [[int(x) for x in rs.randint(1, q, d)] for d in deg]
+    path = str(tmp_path / "big_lists")
+    write(path, N, len(deg), q, deg, rows, coefs)
+    B = 2
+    llr = (rs.rand(B, N, q) * 30).astype(np.float32)
+    llr[1] = np.round(llr[1] * 2) / 2
+    llr -= llr.min(axis=2, keepdims=True)
+    o = orc.Oracle(path)
+    try:
+        dec = pkg.Decoder(pkg.Code(path), nm, nop, 0.3, 3, max_batch=B, early_exit=False)
+    except pkg.EmsError as e:                                                          # (only "does not fit the LDS" is an answer here)
+        assert e.code == pkg.EMS_EUNSUPPORTED and "LDS" in str(e), str(e)
+        pytest.skip(str(e))
+    dec.load_llr(llr)
+    dec.decode(B)
+    d, it, sy = dec.results(B)
+    assert "k_decode_wide" in dec.last_kernel
+    for b in range(B):
+        ref = o.decode(llr[b], nm, nop, 0.3, 3, early_exit=False, want_state=True)
+        assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], b
+        assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), b
+    dec.close()
+
+
+def test_degree_two_checks_with_a_symbol_named_twice_in_a_list(pkg, orc, tmp_path):
+    """dc = 2: a check node's output for one edge IS the other edge's input list (bubble_decoder.c:155-163, :214-222), and when fewer than nm
+    symbols of a node are selectable the entries behind them all carry symbol 0 (NB_LDPC.c:362) -- the reference's in-order scatter lets the
+    last of them stay (bubble_decoder.c:262-265).  Found by the soak (EMS_FUZZ_BLOCKS=300, block 68): lanes scattering such entries at once
+    let whichever the LDS / memory system serves last win (usually the right one, hence a soak to find it); the record now gives every entry
+    the value of the last one with its symbol.  GF(16) nm = 11 with 8 selectable symbols per node, GF(64) nm = 40 with 20, GF(256) 20 / 12."""
+    for q, nm, sel in ((16, 11, 8), (64, 40, 20), (256, 20, 12)):
+        rs = np.random.RandomState(q + nm)
+        N, M = 9, 6
+        rows = [[int(c) for c in rs.choice(N, 2, replace=False)] for _ in range(M)]
+        coefs = [[int(x) for x in rs.randint(1, q, 2)] for _ in range(M)]
+        path = str(tmp_path / ("dc2_%d" % q))
+        write(path, N, M, q, [2] * M, rows, coefs)
+        B = 4
+        llr = (rs.rand(B, N, q) * 30).astype(np.float32)
+        llr -= llr.min(axis=2, keepdims=True)
+        for b in range(B):
+            for n in range(N):
+                llr[b, n, rs.permutation(q)[sel:]] = 1e5                               # q - sel symbols of every node not selectable
+        o = orc.Oracle(path)
+        for ee in (False, True):
+            dec = pkg.Decoder(pkg.Code(path), nm, nm, 0.3, 4, max_batch=B, early_exit=ee)
+            dec.load_llr(llr)
+            dec.decode(B)
+            d, it, sy = dec.results(B)
+            for b in range(B):
+                ref = o.decode(llr[b], nm, nm, 0.3, 4, early_exit=ee, want_state=True)
+                assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], (q, ee, b)
+                assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), (q, ee, b)
+            dec.close()
