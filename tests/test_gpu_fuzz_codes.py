@@ -176,7 +176,7 @@ def test_random_dv2_codes_through_the_v2_flavour(pkg, orc, tmp_path, monkeypatch
     v2 = importlib.import_module("orc_v2")
     rs = np.random.RandomState(6300 + q + dc)
     seen = set()
-    for case in range(6):
+    for case in range(int(os.environ.get("EMS_FUZZ_V2", "6"))):
         path = str(tmp_path / ("v2_%d_%d_%d" % (q, dc, case)))
         N, M = _random_dv2_code(rs, path, q, dc)
         nop = int(rs.choice([nm, nm + 3, 2 * nm, 3 * nm]))
@@ -210,7 +210,7 @@ def test_random_dv2_codes_through_the_v2_flavour(pkg, orc, tmp_path, monkeypatch
     print("v2", (q, dc, nm), sorted(seen))
 
 
-@pytest.mark.parametrize("block", range(4))
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_HARNESS", "4"))))
 def test_c_harness_on_random_codes_equals_the_oracle_simulation(pkg, orc, tmp_path, block):
     """The C Monte-Carlo harness (the reference's argv; frame source, encoder, channel, decode on the GPU, statistics) on the seeded random
     codes of tests/fuzz_codes.py prints the trace of the oracle's simulation -- which tests/test_oracle_fuzz_vs_reference.py holds to the REAL
@@ -306,3 +306,63 @@ def test_degree_two_checks_with_a_symbol_named_twice_in_a_list(pkg, orc, tmp_pat
                 assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], (q, ee, b)
                 assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), (q, ee, b)
             dec.close()
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_MID", "3"))))
+def test_random_mid_size_codes_vs_oracle(pkg, orc, tmp_path, monkeypatch, block):
+    """Random codes with 60..400 check nodes (many dependency levels, every wave of the persistent workgroups busy, done flags and claims across
+    waves) at random workgroup sizes, frames drawn by the oracle's encoder at an SNR where some converge (early exit at different sweeps in
+    one batch) and some do not; whole-frame state against the oracle."""
+    rs = np.random.RandomState(8800 + block)
+    ran = 0
+    for case in range(4):
+        q = int(rs.choice([16, 64, 256]))
+        dcs = [[3], [4], [3, 4, 5], [6], [8], [5, 6, 7, 8], [12, 9]][int(rs.randint(7))]
+        M = int(rs.randint(60, 401))
+        deg = sorted((int(rs.choice(dcs)) for _ in range(M)), reverse=True)
+        E = sum(deg)
+        N = max(2 * M, E // 2)
+        while True:
+            slots = ([int(c) for c in rs.permutation(N)] + [int(c) for c in rs.randint(0, N, max(0, E - N))])[:E]
+            rs.shuffle(slots)
+            rows, k, ok = [], 0, True
+            for d in deg:
+                r = slots[k:k + d]; k += d
+                if len(set(r)) != d:
+                    if rs.rand() < 0.5:                                                # now and then a repeated variable node stays
+                        rows.append(r); continue
+                    ok = False; break
+                rows.append(r)
+            if ok:
+                break
+        coefs = [[int(x) for x in rs.randint(1, q, d)] for d in deg]
+        path = str(tmp_path / ("mid_%d_%d" % (block, case)))
+        write(path, N, M, q, deg, rows, coefs)
+        nm = min(q, int(rs.choice([8, 12, 16, 20])))
+        nop = int(rs.choice([nm + 3, 2 * nm]))
+        itmax = int(rs.randint(3, 9))
+        ee = bool(rs.randint(2))
+        B = int(rs.randint(2, 6))
+        o = orc.Oracle(path)
+        try:
+            sigma = o.sigma(float(rs.choice([3.0, 5.0, 7.0])))
+            rng = orc.Rng(block * 10 + case)
+            frames = [o.draw_frame(rng, sigma) for _ in range(B)]
+        except RuntimeError:                                                           # rank-deficient: no encoder
+            continue
+        noisy = np.stack([f[1] for f in frames])
+        w = int(rs.choice([0, 1, 2, 3, 5]))
+        if w:
+            monkeypatch.setenv("EMS_WAVES", str(w))
+        dec = pkg.Decoder(pkg.Code(path), nm, nop, 0.3, itmax, max_batch=B, early_exit=ee)
+        decide, iters, synd = dec.decode_batch(noisy, sigma)
+        for b in range(B):
+            ref = o.decode(o.llr(noisy[b], sigma), nm, nop, 0.3, itmax, early_exit=ee, want_state=True)
+            ctx = (block, case, q, M, N, deg[0], deg[-1], nm, nop, itmax, ee, w, dec.last_kernel, dec.last_workgroup_waves, b)
+            assert (decide[b] == ref["decide"]).all() and iters[b] == ref["iters"] and synd[b] == ref["synd"], ctx
+            assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
+        dec.close()
+        if w:
+            monkeypatch.delenv("EMS_WAVES")
+        ran += 1
+    assert ran >= 2, ran
