@@ -62,3 +62,34 @@ def test_reference_main_on_the_gpu_library_prints_the_reference_traces(kat, tmp_
     matrix = ("KN_" + k["matrix"]) if k.get("fmt") == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]     # (the library's loader detects the layout itself)
     tr = _run(ESSAI_GPU, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]], str(tmp_path))
     assert tr == [list(t) for t in k["trace"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_BOUNDARY", "2"))))
+def test_reference_main_on_the_gpu_library_on_random_codes(orc, tmp_path, block):
+    """The same executable on the seeded random codes of tests/fuzz_codes.py (mixed check degrees 2..20, three fields, repeated variable
+    nodes): the trace of the oracle's simulation, which tests/test_oracle_fuzz_vs_reference.py holds to the unmodified executable on the same
+    codes.  A rank-deficient matrix stops both before the first frame (tools.c:181-185)."""
+    if not os.path.exists(ESSAI_GPU):
+        pytest.skip("oracle/_ref/essai_gpu is not built (make -C oracle ref, needs /root/reference)")
+    from fuzz_codes import simulation_case
+    ran = 0
+    for seed in range(block * 10, block * 10 + 10):
+        path = str(tmp_path / ("rnd_%d" % seed))
+        frames, it, eb, nm, off, nop = simulation_case(seed, path)
+        os.makedirs(os.path.join(str(tmp_path), "data"), exist_ok=True)
+        out = subprocess.run([ESSAI_GPU] + [str(a) for a in (frames, it, path, eb, nm, off, nop)], cwd=str(tmp_path), input=b"\n",
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        txt = out.stdout.decode("latin-1")
+        tr = [[int(m.group(1)), int(m.group(3)), m.group(4)] for m in
+              re.finditer(r"<\d+> FER= (\d+) / (\d+) = [\d.]+ BER= (\d+) / x = [\d.]+\s+avr_it=([\d.]+)", txt)]
+        o = orc.Oracle(path)
+        try:
+            rec = o.sim(orc.Rng(0), eb, nm, nop, off, it, frames)
+        except RuntimeError as e:
+            assert "not full rank" in str(e) and "not full rank" in txt and not tr, (seed, str(e), txt[-300:])
+            continue
+        assert out.returncode == 0, (seed, out.stderr.decode()[-1000:])
+        assert tr == [list(t) for t in orc.trace_from_records(rec, o.K, o.logq)], (seed, nm, nop, off, it, eb)
+        ran += 1
+    assert ran >= 7, ran
