@@ -77,6 +77,18 @@ def test_random_codes_vs_oracle(pkg, orc, tmp_path, block):
             assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], ctx
             assert dec.app(b).tobytes() == ref["app"].tobytes(), ctx
             assert dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
+        if case % 3 == 0 and nm > 6:                                                   # ems_set_params on the same handle: shorter messages, other NbOper / offset
+            nm2 = int(rs.randint(5, nm))
+            nop2 = int(rs.choice([nm2, nm2 + 3, 2 * nm2]))
+            dec.set_params(nm=nm2, nbOper=nop2, offset=0.5)
+            dec.load_llr(llr)
+            dec.decode(B)
+            d, it, sy = dec.results(B)
+            for b in range(B):
+                ref = o.decode(llr[b], nm2, nop2, 0.5, itmax, early_exit=ee, want_state=True)
+                ctx = (block, case, "set_params", q, deg, nm, nm2, nop2, itmax, ee, rep, dec.last_kernel, b)
+                assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], ctx
+                assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
         dec.close()
         ran += 1
     print("block %d: %d of 16 cases ran, kernels %s" % (block, ran, sorted(kernels)))
