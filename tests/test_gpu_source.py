@@ -189,3 +189,37 @@ def test_source_error_paths(pkg, refapi):
         dec.source_draw(1, 0, 9, 0.5)
     dec.source_draw(1, 0, 8, 0.5)
     dec.close(); s.close()
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_SOURCE", "2"))))
+def test_source_on_random_codes(pkg, refapi, osrc, orc, tmp_path, block):
+    """The device-side encoder / noise source on the seeded random codes of tests/fuzz_codes.py (mixed check degrees, three fields, repeated
+    variable nodes, column degrees 0..n): codewords bit for bit against the source oracle, noisy samples within the float tolerance, and
+    every frame in the null space the reference's encoder sees (one coefficient per (row, column), tools.c:143-230)."""
+    from fuzz_codes import simulation_case
+    ran = 0
+    for seed in range(block * 10, block * 10 + 10):
+        path = str(tmp_path / ("rnd_%d" % seed))
+        frames, it, eb, nm, off, nop = simulation_case(seed, path)
+        try:                                                     # a rank-deficient matrix makes GaussianElimination exit() as the reference's does
+            orc.Oracle(path).draw_frame(orc.Rng(0), 0.5)         # (tools.c:181-185): ask the oracle first
+        except RuntimeError as e:
+            assert "not full rank" in str(e), (seed, str(e))
+            continue
+        s = refapi.RefSession(path, nm, need_encoder=True)
+        matUT = np.ctypeslib.as_array(s.code.matUT[0], shape=(s.M * s.N,)).reshape(s.M, s.N).copy()
+        perm = np.ctypeslib.as_array(s.code.Perm, shape=(s.N,)).copy()
+        so = osrc.SourceOracle(path, matUT, perm)
+        B = 5 + seed % 9
+        dec = pkg.Decoder(pkg.Code(path), nm, nop, off, it, max_batch=B)
+        dec.source_attach(s)
+        sigma = 0.5 + 0.05 * (seed % 7)
+        dec.source_draw(1000 + seed, 3 * seed, B, sigma)
+        cw, noisy = dec.source_get(B)
+        for b in range(B):
+            ocw, onoisy = so.frame(1000 + seed, 3 * seed + b, sigma)
+            assert (cw[b] == ocw).all(), (seed, b)
+            assert np.abs(noisy[b] - onoisy).max() <= NOISE_ATOL, (seed, b)
+        dec.close(); s.close()
+        ran += 1
+    assert ran >= 7, ran
