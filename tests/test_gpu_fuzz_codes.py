@@ -378,3 +378,57 @@ def test_random_mid_size_codes_vs_oracle(pkg, orc, tmp_path, monkeypatch, block)
             monkeypatch.delenv("EMS_WAVES")
         ran += 1
     assert ran >= 2, ran
+
+
+def test_more_than_255_sweeps(pkg, orc, tmp_path, monkeypatch):
+    """NbIterMax = 300 with early exit off: the persistent kernels tag their per-task done flags with (sweep + 1) & 0xFF (the lane-serial GF(16)
+    kernel counts sweeps per group instead) -- the tags wrap, the order of the visits must not.  N96 on the one-visit, two-visit and two-frame
+    kernels, a GF(16) dc = 8 code on the lane-serial and two-visit kernels, whole-frame state against the oracle after 300 sweeps."""
+    MAT = os.path.join(ROOT, "tests", "golden", "matrices")
+
+    def run(name, nm, nop, B, ebn):
+        path = os.path.join(MAT, name)
+        o = orc.Oracle(path)
+        sigma = o.sigma(ebn)
+        rng = orc.Rng(5)
+        frames = [o.draw_frame(rng, sigma) for _ in range(B)]
+        noisy = np.stack([f[1] for f in frames])
+        dec = pkg.Decoder(pkg.Code(path), nm, nop, 0.3, 300, max_batch=B, early_exit=False)
+        d, it, sy = dec.decode_batch(noisy, sigma)
+        for b in range(B):
+            ref = o.decode(o.llr(noisy[b], sigma), nm, nop, 0.3, 300, early_exit=False, want_state=True)
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], (name, dec.last_kernel, b)
+            assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), (name, dec.last_kernel, b)
+        k = dec.last_kernel
+        dec.close()
+        return k
+
+    seen = {run("N96_K48_GF64", 16, 32, 3, -3.0)}
+    for knob, val in (("EMS_DUAL", "1"), ("EMS_TWIN", "1")):
+        monkeypatch.setenv(knob, val)
+        seen.add(run("N96_K48_GF64", 16, 32, 3, -3.0))
+        monkeypatch.delenv(knob)
+    # GF(16) / dc = 8 / nm = 8 on a random regular graph, LLR block as the input
+    rs = np.random.RandomState(300)
+    path = str(tmp_path / "gf16_dc8")
+    N, M = _random_regular_code(rs, path, 16, 8)
+    llr = (rs.rand(2, N, 16) * 20).astype(np.float32)
+    llr -= llr.min(axis=2, keepdims=True)
+    o = orc.Oracle(path)
+    refs = [o.decode(llr[b], 8, 16, 0.3, 300, early_exit=False, want_state=True) for b in range(2)]
+    for kn in ({}, {"EMS_Q16T": "0"}):
+        for k, v in kn.items():
+            monkeypatch.setenv(k, v)
+        dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 300, max_batch=2, early_exit=False)
+        dec.load_llr(llr)
+        dec.decode(2)
+        d, it, sy = dec.results(2)
+        for b in range(2):
+            assert (d[b] == refs[b]["decide"]).all() and it[b] == refs[b]["iters"] and sy[b] == refs[b]["synd"], (dec.last_kernel, b)
+            assert dec.app(b).tobytes() == refs[b]["app"].tobytes() and dec.ctov(b).tobytes() == refs[b]["ctov"].tobytes(), (dec.last_kernel, b)
+        seen.add(dec.last_kernel)
+        dec.close()
+        for k in kn:
+            monkeypatch.delenv(k)
+    print(sorted(seen))
+    assert len(seen) >= 5, seen
