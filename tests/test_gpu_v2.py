@@ -262,3 +262,10 @@ def test_v2_harness_prints_the_lines_of_the_v2_executable(pkg, tmp_path, case, b
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = re.findall(r"<\d+> FER= \d+/ \d+ = \S+ BER= \d+/ \d+ = \S+", out.stdout.decode("latin-1"))
     assert lines == k["lines"]
+
+
+def test_v2_more_than_255_iterations(pkg, v2, monkeypatch):
+    """NbIterMax = 300, early exit off: the done-flag tags of the persistent v2 kernels wrap (see tests/test_gpu_fuzz_codes.py)."""
+    _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 12, 24, 0.5, 300, [(1.3, 1), (1.0, 2)], early_exit=False)
+    monkeypatch.setenv("EMS_DUAL", "2")
+    _check_frames(pkg, v2, "KN_N128_K64_GF256.txt", 256, 8, 20, 40, 0.3, 300, [(1.2, 3)], early_exit=False)
