@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from make_irregular_matrix import write  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("EMS_FUZZ_SEED", "0"))          # shifts every seeded stream of this file (soak runs)
 
 DEGREE_SETS = [[2], [3], [4], [2, 3], [3, 4, 5], [5, 6, 7, 8], [8], [9, 10, 12], [13, 16], [17, 18, 20], [24, 19, 17], [2, 9, 17], [33, 20, 40]]
 
@@ -42,7 +43,7 @@ def _random_code(rs, path):
 
 @pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_BLOCKS", "12"))))      # (EMS_FUZZ_BLOCKS=300: a one-minute soak of 4800 codes)
 def test_random_codes_vs_oracle(pkg, orc, tmp_path, block):
-    rs = np.random.RandomState(4100 + block)
+    rs = np.random.RandomState(4100 + block + SEED)
     ran = 0
     kernels = set()
     for case in range(16):
@@ -127,7 +128,7 @@ def test_random_regular_codes_through_the_specialised_kernels(pkg, orc, tmp_path
     dependency flags of the persistent kernels see topologies the fixed matrices do not have) through every kernel family built for the
     shape -- one visit per wave, two visits, two frames, the lane-serial GF(16) kernel -- whole-frame state against the oracle."""
     q, dc, nm, knobs = FAMILIES[fam]
-    rs = np.random.RandomState(5200 + fam)
+    rs = np.random.RandomState(5200 + fam + SEED)
     seen = set()
     for case in range(int(os.environ.get("EMS_FUZZ_REGULAR", "14"))):
         path = str(tmp_path / ("reg_%d_%d" % (fam, case)))
@@ -186,7 +187,7 @@ def test_random_dv2_codes_through_the_v2_flavour(pkg, orc, tmp_path, monkeypatch
     import importlib
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     v2 = importlib.import_module("orc_v2")
-    rs = np.random.RandomState(6300 + q + dc)
+    rs = np.random.RandomState(6300 + q + dc + SEED)
     seen = set()
     for case in range(int(os.environ.get("EMS_FUZZ_V2", "6"))):
         path = str(tmp_path / ("v2_%d_%d_%d" % (q, dc, case)))
@@ -325,7 +326,7 @@ def test_random_mid_size_codes_vs_oracle(pkg, orc, tmp_path, monkeypatch, block)
     """Random codes with 60..400 check nodes (many dependency levels, every wave of the persistent workgroups busy, done flags and claims across
     waves) at random workgroup sizes, frames drawn by the oracle's encoder at an SNR where some converge (early exit at different sweeps in
     one batch) and some do not; whole-frame state against the oracle."""
-    rs = np.random.RandomState(8800 + block)
+    rs = np.random.RandomState(8800 + block + SEED)
     ran = 0
     for case in range(4):
         q = int(rs.choice([16, 64, 256]))
