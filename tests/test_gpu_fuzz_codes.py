@@ -251,6 +251,9 @@ def test_c_harness_on_random_codes_equals_the_oracle_simulation(pkg, orc, tmp_pa
         assert out.returncode == 0, (seed, out.stderr.decode()[-1000:])
         mine = orc.trace_from_records(rec, o.K, o.logq)
         assert [list(t) for t in tr] == [list(t) for t in mine], (seed, nm, nop, off, it, eb)
+        if os.path.exists(orc.ref_binary("ubs")):                                      # ... and, live, the REAL executable's (its binary travels with oracle/_ref)
+            real = orc.run_reference_binary("ubs", frames, it, path, eb, nm, off, nop, timeout=120)
+            assert [list(t) for t in real] == [list(t) for t in tr], (seed, "real executable", nm, nop, off, it, eb)
         ran += 1
     assert ran >= 7, ran
 

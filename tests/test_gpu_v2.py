@@ -269,3 +269,42 @@ def test_v2_more_than_255_iterations(pkg, v2, monkeypatch):
     _check_frames(pkg, v2, "N96_K48_GF64", 64, 6, 12, 24, 0.5, 300, [(1.3, 1), (1.0, 2)], early_exit=False)
     monkeypatch.setenv("EMS_DUAL", "2")
     _check_frames(pkg, v2, "KN_N128_K64_GF256.txt", 256, 8, 20, 40, 0.3, 300, [(1.2, 3)], early_exit=False)
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_V2_HARNESS", "2"))))
+def test_v2_harness_on_random_codes_equals_the_real_executable(pkg, tmp_path, block):
+    """Live on the GPU box: the REAL older-generation executable (oracle/_ref/essai_v2, built from /root/reference where it lies and carried
+    along as a binary) and csrc/harness/ems_sim_v2.c with the same argv on seeded random (2, dc)-regular GF(256) codes -- every statistics
+    line (BER samples at iterations 9 / 19 / 29 / 39 / 49, the "> 12 bit errors" frame rule), frame after frame, at SNRs where frames fail."""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_irregular_matrix import write
+    exe = os.path.join(ROOT, "oracle", "_ref", "essai_v2")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/essai_v2 is not built (make -C oracle ref, needs /root/reference)")
+    rs = np.random.RandomState(7700 + block)
+    pat = r"<\d+> FER= \d+/ \d+ = \S+ BER= \d+/ \d+ = \S+"
+    for case in range(5):
+        dc = int(rs.choice([3, 4, 6, 8, 12]))
+        M = 2 * int(rs.randint(4, 24))
+        N = M * dc // 2
+        while True:
+            slots = [int(c) for c in rs.permutation(np.repeat(np.arange(N), 2))]
+            rows = [slots[m * dc:(m + 1) * dc] for m in range(M)]
+            if all(len(set(r)) == dc for r in rows):
+                break
+        coefs = [[int(x) for x in rs.randint(1, 256, dc)] for _ in range(M)]
+        path = str(tmp_path / ("v2h_%d_%d" % (block, case)))
+        write(path, N, M, 256, [dc] * M, rows, coefs)
+        nm = int(rs.choice([8, 12, 20]))
+        argv = [str(a) for a in (int(rs.randint(6, 15)), int(rs.choice([12, 25, 50])), path, float(rs.choice([4.0, 6.0, 7.5, 9.0])), nm, float(rs.choice([0.3, 1.0])),
+                                 int(rs.choice([nm + 3, 2 * nm])))]
+        ref = subprocess.run([exe] + argv, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout.decode("latin-1")
+        want = re.findall(pat, ref)
+        if not want:                                             # (a rank-deficient random matrix: the executable stops before the first frame)
+            continue
+        out = subprocess.run([pkg.SIM_V2_PATH] + argv, cwd=str(tmp_path), env=dict(os.environ, EMS_BATCH=str(2 + case)), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=300)
+        assert out.returncode == 0, (argv, out.stderr.decode()[-1500:])
+        assert re.findall(pat, out.stdout.decode("latin-1")) == want, (block, case, argv)
