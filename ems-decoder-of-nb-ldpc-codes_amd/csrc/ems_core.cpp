@@ -77,38 +77,39 @@ int ilog2(int q)
 }
 
 // forward/backward/merge task table (see cn_core in ems_kernels.hip)
+// LDS of one compute unit, from the device (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor; 160 KiB on gfx950): what a workgroup, and
+// the workgroups sharing a CU, can be given.  kLdsGrant: the unit the hardware hands LDS out in -- MEASURED on this part (27 KiB workgroups
+// ran five to a CU, 13 KiB ones eleven; profiles/NOTES.md round 2), not a property the runtime reports.
+constexpr size_t kLdsGrant = 2048;
+static size_t device_lds_per_cu(int device)
+{
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess || v <= 0) return 160 * 1024;
+    return (size_t)v;
+}
+static inline size_t lds_granted(size_t bytes) { return (bytes + kLdsGrant - 1) & ~(kLdsGrant - 1); }
+
 struct CnSchedule {
     int nsteps = 0, n_lists = 0;
-    std::vector<int8_t> tasks; // [nsteps][4][3]
     int8_t out_list[16];
 };
 
+// The forward / backward / merge schedule of bubble_decoder.c:166-227 as the kernels need it from the host: the number of stages and
+// of lists, and for dc <= 16 the list that holds each edge's output (bubble_decoder.c:231-254; list ids as kernels/ems_cn.inc:
+// list_P / list_S / list_M).  The per-stage task tables themselves are built on the device (cn_sched_build, cn_task) -- the host copy
+// round 1 uploaded had no reader left and packed list ids into int8 (ids reach 4 dc - 6 = 250 at dc = 64), so it is gone.
 int build_cn_schedule(int dc, CnSchedule &s)
 {
     if (dc < 2 || dc > EMS_MAX_DC) return fail(EMS_EUNSUPPORTED, "check-node degree %d not supported (2..%d)", dc, EMS_MAX_DC);
-    auto in = [&](int i) { return i; };
-    auto Pl = [&](int k) { return k == 0 ? in(0) : dc + (k - 1); };
-    auto Sl = [&](int k) { return k == dc - 1 ? in(dc - 1) : dc + (dc - 2) + (k - 1); };
+    auto Pl = [&](int k) { return k == 0 ? 0 : dc + (k - 1); };
+    auto Sl = [&](int k) { return k == dc - 1 ? dc - 1 : dc + (dc - 2) + (k - 1); };
     auto Ml = [&](int k) { return dc + 2 * (dc - 2) + k; };
     s.nsteps = dc - 2;
     s.n_lists = dc + 3 * (dc - 2);
-    s.tasks.assign((size_t)std::max(s.nsteps, 1) * 12, (int8_t)-1);
-    for (int t = 1; t <= dc - 2; ++t) {
-        int8_t *row = &s.tasks[(size_t)(t - 1) * 12];
-        int slot = 0;
-        auto put = [&](int a, int b, int o) {
-            row[slot * 3 + 0] = (int8_t)a;
-            row[slot * 3 + 1] = (int8_t)b;
-            row[slot * 3 + 2] = (int8_t)o;
-            ++slot;
-        };
-        put(Pl(t - 1), in(t), Pl(t));                     // bubble_decoder.c:192 forward
-        put(Sl(dc - t), in(dc - 1 - t), Sl(dc - 1 - t));  // bubble_decoder.c:198 backward
-        for (int k = 0; k <= dc - 3; ++k)                 // bubble_decoder.c:221 merges, as soon as ready
-            if (std::max(k, dc - 3 - k) + 1 == t) {
-                if (slot >= 4) return fail(EMS_EUNSUPPORTED, "internal: more than 4 tasks in a step");
-                put(Pl(k), Sl(k + 2), Ml(k));
-            }
+    for (int t = 1; t <= dc - 2; ++t) {                     // at most four tasks per stage: forward, backward, the merges that became ready
+        int slot = 2;
+        for (int k = 0; k <= dc - 3; ++k)
+            if (std::max(k, dc - 3 - k) + 1 == t && ++slot > 4) return fail(EMS_EUNSUPPORTED, "internal: more than 4 tasks in a step");
     }
     memset(s.out_list, 0, sizeof s.out_list);
     for (int t = 0; t < dc && t < 16; ++t)                  // (degrees above 16: k_decode_wide / k_cn_unit compute the list from the degree)
@@ -182,6 +183,7 @@ template <typename T> struct DevBuf {
 
 struct ems_handle {
     int device = 0, max_batch = 0, nm_alloc = 0, n_cu = 0;
+    size_t lds_cu = 160 * 1024;          // LDS of one CU, asked from the device at create (hipDeviceAttributeMaxSharedMemoryPerMultiprocessor; gfx950: 160 KiB)
     int N = 0, M = 0, K = 0, E = 0, q = 0, logq = 0, dc = 0;
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
@@ -200,7 +202,6 @@ struct ems_handle {
     CnSchedule cs;
     DevBuf<int> d_lvl_ptr, d_lvl_cn, d_cn_vn, d_iters, d_synd, d_cw, d_nberr, d_t_vn, d_t_lh, d_t_pred, d_t_cnp, d_iso_vn, d_p_cn, d_p_vn, d_p_lh, d_p_pred;
     DevBuf<uint8_t> d_cn_lh, d_i2b, d_b2i, d_ctov, d_decide;
-    DevBuf<int8_t> d_sched;
     DevBuf<float> d_app, d_noisy, d_scratch, d_att, d_ctable;   // d_att / d_ctable: constellation front ends (allocated on first use)
     DevBuf<unsigned long long> d_stamps;
     // v2 flavour (allocated on first ems_v2_load_likelihood)
@@ -431,11 +432,11 @@ int refresh_plan(ems_handle *h)
     const int wcap = h->wide ? 8 : ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
     if (h->tune.waves > 0) waves = std::max(1, std::min(wcap, h->tune.waves));                  // ems_set_tuning
-    const size_t lds_cap = 160 * 1024;
+    const size_t lds_cap = h->lds_cu;
     while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap) --waves;
     if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > lds_cap)
-        return fail(EMS_EUNSUPPORTED, "check degree %d with nm = %d over GF(%d): the %zu bytes of message lists of one check node do not fit the 160 KiB of LDS", h->dc,
-                    p.nm, h->q, ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves));
+        return fail(EMS_EUNSUPPORTED, "check degree %d with nm = %d over GF(%d): the %zu bytes of message lists of one check node do not fit the %zu KiB of LDS", h->dc,
+                    p.nm, h->q, ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves), lds_cap / 1024);
     P.waves_per_wg = waves;
     P.occ4 = 0;
     P.stamps = h->d_stamps.p;
@@ -665,7 +666,7 @@ void ems_destroy(ems_handle *h)
     for (DevBuf<int> *b : {&h->d_src_tptr, &h->d_src_tcol, &h->d_src_rptr, &h->d_src_rcol, &h->d_src_perm}) b->release();
     for (DevBuf<uint8_t> *b : {&h->d_src_tcoef, &h->d_src_rcoef, &h->d_src_diag, &h->d_src_sym, &h->d_src_rhs}) b->release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
-    h->d_ctov.release(); h->d_decide.release(); h->d_sched.release(); h->d_app.release(); h->d_noisy.release();
+    h->d_ctov.release(); h->d_decide.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
     h->d_v2_p_dst.release(); h->d_v2_p_last.release(); h->d_v2_snap.release();
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
@@ -692,6 +693,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     ems_handle *h = new ems_handle;
     h->device = device; h->max_batch = max_batch; h->nm_alloc = prm->nm; h->prm = *prm;
     (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    h->lds_cu = device_lds_per_cu(device);
     {   // developer variables, read here and nowhere else (ems_set_tuning is the API)
         auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
         h->tune.dual = env_int("EMS_DUAL", -1);
@@ -761,7 +763,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     const size_t B = (size_t)max_batch;
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
-        (r = h->d_sched.upload(h->cs.tasks)) || (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_p_cn.upload(h->p_cn)) || (r = h->d_p_vn.upload(h->p_vn)) ||
+        (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_p_cn.upload(h->p_cn)) || (r = h->d_p_vn.upload(h->p_vn)) ||
         (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
@@ -877,6 +879,28 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
 // kernels run several 4-wave workgroups per CU instead (one wave of every workgroup on each SIMD; a 6-wave
 // workgroup would not spread evenly and two of them cannot share a CU): 3 frames per CU with the ~143-VGPR
 // build, 4 with the 128-VGPR build where it exists and the batch fills it.  Other kernels keep the plan's shape.
+// Frames-per-CU thresholds of the dc <= 4 kernels' workgroup shapes, per (q, dc, nm).  Only the first row was MEASURED (the headline code,
+// frames/s at batch 256 / 512 / 768 / 1024 / 1536 on every shape); the others INHERIT it -- same kernels, same LDS and
+// VGPR budgets per wave within a few hundred bytes -- and say so; a shape measured on another (q, dc, nm) gets a row of its own here.
+struct ShapeRule {
+    int q, dc, nm;              // 0 = any
+    int dual2_from;             // >= this many frames per CU: two-visit kernel in 2-wave workgroups, six to a CU
+    int dual4_lo, dual4_hi;     // this range of frames per CU: the same kernel in 4-wave workgroups, three to a CU
+    int occ4_from;              // >= : the 128-VGPR one-visit build, four 4-wave workgroups per CU (where it exists)
+    int wg4_from;               // >= : the one-visit kernel in 4-wave workgroups, three to a CU
+    bool measured;
+};
+static const ShapeRule kShapeRules[] = {
+    {256, 4, 20, 5, 2, 3, 4, 3, true},      // Ahmed_64800_R12_GF256: 2811 / 3636 frames/s at batch 512 / 768 on dual4 against 2403 / 2922; 3295 on occ4 at 1024; 3926 on dual2 at 1536
+    {0, 0, 0, 5, 2, 3, 4, 3, false},        // everything else: inherited
+};
+static const ShapeRule &shape_rule(int q, int dc, int nm)
+{
+    for (const ShapeRule &r : kShapeRules)
+        if ((r.q == 0 || r.q == q) && (r.dc == 0 || r.dc == dc) && (r.nm == 0 || r.nm == nm)) return r;
+    return kShapeRules[sizeof kShapeRules / sizeof kShapeRules[0] - 1];
+}
+
 static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_dual = true)
 {
     P.occ4 = 0;
@@ -887,7 +911,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
     };
-    const size_t lds_cap = 160 * 1024;
+    const size_t lds_cap = h->lds_cu;
     auto dual_fit = [&](int waves) {                          // largest workgroup of the dual kernel within LDS and its launch bound
         waves = std::min(waves, ems_dual_max_waves(h->dc));
         while (waves > 1 && ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, waves) > lds_cap) --waves;
@@ -929,16 +953,17 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     if (ems_lpe_for(h->dc) != 16 || P.waves_per_wg < 12 || h->n_cu <= 0) return;   // (the batch shapes below belong to the dc <= 4 kernels)
     const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
+    const ShapeRule &R = shape_rule(h->q, h->dc, P.nm);
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
-    if (allow_dual && !no_dual && fpc >= 5 && ems_has_dual_kernel(P) &&
-        6 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(2); return; }   // (LDS is granted in 2 KiB units: 27 KiB workgroups ran five to a CU, 13 KiB ones eleven)
+    if (allow_dual && !no_dual && fpc >= R.dual2_from && ems_has_dual_kernel(P) &&
+        6 * lds_granted(ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2)) <= lds_cap) { go_dual(2); return; }   // (six workgroups of their granted size, see kLdsGrant)
     // two or three frames per CU: the same kernel in 4-wave workgroups, three to a CU (measured on the headline code, frames/s at
     // batch 512 / 768: 2811 / 3636 against 2403 / 2922 for the one-visit shapes; at 256 the 12-wave one-visit workgroup wins,
     // 2391 against 1559, and at 1024 its 128-VGPR 4-wave build, 3295 against 2964)
-    if (allow_dual && !no_dual && fpc >= 2 && fpc <= 3 && ems_has_dual_kernel(P) &&
-        3 * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 4) + 2047) & ~(size_t)2047) <= lds_cap) { go_dual(4); return; }
-    if (fpc >= 4 && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
-    else if (fpc >= 3 && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
+    if (allow_dual && !no_dual && fpc >= R.dual4_lo && fpc <= R.dual4_hi && ems_has_dual_kernel(P) &&
+        3 * lds_granted(ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 4)) <= lds_cap) { go_dual(4); return; }
+    if (fpc >= R.occ4_from && 4 * wg4 <= lds_cap && ems_has_occ4_kernel(P)) { P.waves_per_wg = 4; P.occ4 = 1; }
+    else if (fpc >= R.wg4_from && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }
 
 int ems_decode(ems_handle *h, int B)
@@ -1140,8 +1165,8 @@ static int v2_prepare(ems_handle *h)
 {
     if (h->v2_ready) return EMS_OK;
     if (h->repeats) return fail(EMS_EUNSUPPORTED, "v2 flavour: a check node lists a variable node twice (v2.c:2157 pairs the two edges of a variable node across check nodes)");
-    if (!h->regular) return fail(EMS_EUNSUPPORTED, "v2 flavour: irregular check degrees are not built");
-    if (!ems_lpe_for(h->dc)) return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d > 16 is not built", h->dc);
+    // (round 5: irregular (2, dc) codes and check degrees above 16 run k_decode_v2_wide, per-visit degrees; v2.c:1756-1852 loops over
+    //  rowDegree[node] with no cap.  h->dc is the LARGEST degree and the stride of the per-(task, edge) tables.)
     if (h->q != 64 && h->q != 256) return fail(EMS_EUNSUPPORTED, "v2 flavour: GF(%d) is not built (GF(64), GF(256))", h->q);
     // the reference's Flag trick (v2.c:2157) needs exactly two edges per variable node
     std::vector<int> deg(h->N, 0);
@@ -1153,12 +1178,13 @@ static int v2_prepare(ems_handle *h)
     }
     for (int v = 0; v < h->N; ++v)
         if (deg[v] != 2) return fail(EMS_EUNSUPPORTED, "v2 flavour: variable node %d has %d edges, 2 required", v, deg[v]);
-    h->v2_t_dst.resize(h->E);
-    h->v2_t_last.resize(h->E);
+    h->v2_t_dst.assign((size_t)h->M * h->dc, 0);
+    h->v2_t_last.assign((size_t)h->M * h->dc, 0);
     for (int i = 0; i < h->M; ++i) {
         const int m = h->t_cnp[i] & 0xFFFFFF;
-        for (int k = 0; k < h->dc; ++k) {
-            const int e = m * h->dc + k, v = h->cn_vn[e];
+        const int e_first = h->row_ptr[m], dm = h->row_ptr[m + 1] - e_first;
+        for (int k = 0; k < h->dc; ++k) {                                  // (rows beyond the check node's own degree repeat its last edge, as t_vn / t_lh do)
+            const int e = e_first + std::min(k, dm - 1), v = h->cn_vn[e];
             const int a = h->v2_vn_edge[(size_t)v * 2], b = h->v2_vn_edge[(size_t)v * 2 + 1];
             h->v2_t_dst[(size_t)i * h->dc + k] = (a == e) ? b : a;         // the first visitor writes the second edge and vice versa
             h->v2_t_last[(size_t)i * h->dc + k] = (e == b) ? 1 : 0;          // edges are numbered in visiting order: the higher one comes last
@@ -1295,11 +1321,12 @@ int ems_v2_decode(ems_handle *h, int B)
         const long fpc = h->n_cu > 0 ? ((long)B + h->n_cu - 1) / h->n_cu : 0;
         // two or three frames per CU: 4-wave workgroups of it, three to a CU (measured at batch 512 / 768: 2418 / 3112 frames/s
         // against 1843 / 2319 for the one-visit shapes; at 1024 the one-visit 4-wave shape wins, 2617 against 2439)
-        const bool mid = fpc >= 2 && fpc <= 3;
-        const bool want = td >= 0 ? td > 0 : (fpc >= 5 || mid);
+        const ShapeRule &R = shape_rule(h->q, h->dc, P.nm);
+        const bool mid = fpc >= R.dual4_lo && fpc <= R.dual4_hi;
+        const bool want = td >= 0 ? td > 0 : (fpc >= R.dual2_from || mid);
         const int wv = td > 0 ? std::min(4, td) : (mid ? 4 : 2);
         if (want && h->tune.waves <= 0 && ems_has_v2_dual_kernel(P) &&
-            (wv == 4 ? 3 : 6) * ((ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, wv == 4 ? 4 : 2) + 2047) & ~(size_t)2047) <= (size_t)160 * 1024) {
+            (wv == 4 ? 3 : 6) * lds_granted(ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, wv == 4 ? 4 : 2)) <= h->lds_cu) {
             P.dual = 1; P.occ4 = 0;
             P.waves_per_wg = wv;
             P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
@@ -1415,7 +1442,7 @@ int ems_debug_dump(ems_handle *h)
     if (!h) return EMS_EINVAL;
 #define D(x) fprintf(stderr, "  %-10s %p .. +%zu\n", #x, (void *)h->x.p, h->x.n * sizeof(*h->x.p))
     D(d_app); D(d_ctov); D(d_decide); D(d_iters); D(d_synd); D(d_noisy); D(d_cw); D(d_nberr); D(d_lvl_ptr); D(d_lvl_cn);
-    D(d_cn_vn); D(d_cn_lh); D(d_i2b); D(d_b2i); D(d_t_vn); D(d_t_lh); D(d_t_pred); D(d_sched); D(d_scratch); D(d_stamps);
+    D(d_cn_vn); D(d_cn_lh); D(d_i2b); D(d_b2i); D(d_t_vn); D(d_t_lh); D(d_t_pred); D(d_scratch); D(d_stamps);
 #undef D
     return EMS_OK;
 }
@@ -1500,7 +1527,8 @@ int ems_suggest_batch(const ems_code_desc *c, const ems_params *prm, int device,
     long fpc;
     if (per_frame < (1u << 20)) fpc = 32;                         // short codes: state lives in the caches, waves are what they want (N = 96: 8192 frames)
     else if (generic_only) fpc = 1;                               // one workgroup of the generic kernel per CU
-    else if (ems_has_dual_kernel(P)) fpc = dc == 8 ? 1 : 6;       // GF(16) dc 8: flat from 256 to 2048 frames; GF(256) dc 4: six 2-wave workgroups per CU
+    else if (q == 16 && dc == 8 && prm->nm == 8 && prm->nbOper >= 1) fpc = 3;   // k_decode_q16t (the default for this shape): 4-wave workgroups, three to a CU, from three frames per CU on (11.5-11.8e3 against 11.05e3 frames/s at one, see shape_for_batch)
+    else if (ems_has_dual_kernel(P)) fpc = dc == 8 ? 1 : 6;       // GF(256) dc 4: six 2-wave workgroups per CU (dc 8 on the two-visit kernel: flat from 256 to 2048 frames)
     else fpc = ems_lpe_for(dc) == 16 ? 3 : 1;                     // one-visit kernels: three 4-wave workgroups per CU (dc <= 4), else one workgroup per CU
     long b = fpc * n_cu;
     const size_t budget = free_b / 10 * 8 / (size_t)handles;
@@ -1570,10 +1598,9 @@ int ems_check_node(int GF, int dc, int nm, int nbOper, float offset, const int *
     int *dcoef = t.up(coef, dc), *dg = t.up(vtoc_gf, (size_t)dc * nm);
     float *dl = t.up(vtoc_llr, (size_t)dc * nm), *dout = t.up<float>(nullptr, (size_t)dc * GF);
     uint8_t *da = t.up(i2b, 256), *db = t.up(b2i, 256);
-    int8_t *ds = t.up(cs.tasks.data(), cs.tasks.size());
-    if (!dcoef || !dg || !dl || !dout || !da || !db || !ds) return fail(EMS_ENOMEM, "device allocation failed");
+    if (!dcoef || !dg || !dl || !dout || !da || !db) return fail(EMS_ENOMEM, "device allocation failed");
     EmsPlan P{};
-    P.q = GF; P.dc = dc; P.nm = nm; P.nbOper = nbOper; P.offset = offset; P.nsteps = cs.nsteps; (void)ds;
+    P.q = GF; P.dc = dc; P.nm = nm; P.nbOper = nbOper; P.offset = offset; P.nsteps = cs.nsteps;
     P.n_lists = cs.n_lists; memcpy(P.out_list, cs.out_list, sizeof P.out_list);
     P.idx2bin = da; P.bin2idx = db;
     HIP_TRY(ems_launch_cn_unit(P, dcoef, dl, dg, dout, nullptr));

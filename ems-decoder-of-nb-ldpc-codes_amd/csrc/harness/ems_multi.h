@@ -7,6 +7,17 @@
  * A device thread keeps the next round's batch in flight while it collects the current one (launch r+1, then collect r): host-side
  * frame generation and the tail of an early-exit batch overlap the next launch.  A round launched ahead of the stop is drained and
  * dropped, like a frame the reference never drew.
+ *
+ * The collective and the launch order (round 5).  The decode kernel is persistent (one workgroup per frame, resident until its frame is
+ * done), so a collective kernel queued BEHIND round r+1's launch gets a CU only when workgroups of r+1 retire: at once in the usual
+ * early-exit run, but not before r+1 ENDS when no frame of it converges (low SNR; fixed work) -- a host that waits for the all-reduce
+ * of round r right after issuing it would then serialise the rounds.  Two ways out, both here:
+ *   * allreduce_begin / allreduce_end (what ems_sim.c gives for RCCL): the all-reduce of round r is ISSUED right after round r is
+ *     collected and WAITED FOR one round later, after round r+1 is collected -- by then it has certainly had its CU.  The global stop is
+ *     therefore decided one round late (one more round is drained and dropped at the end of a simulation; the ordered tally never
+ *     counts a frame behind the 40th erroneous one anyway).
+ *   * allreduce alone (synchronous; a host-side sum under a barrier, as tests/ctest/test_tally.c and EMS_ALLREDUCE=host): nothing is
+ *     queued on the device, the stop is decided in the round itself.
  */
 #ifndef EMS_MULTI_H
 #define EMS_MULTI_H
@@ -23,11 +34,16 @@ typedef struct {
     int (*launch)(void *ctx, int dev, int slot, long long first, int count);
     /* wait for that slot and fill res[0..count); res == NULL: drain only (the batch is dropped) */
     int (*collect)(void *ctx, int dev, int slot, int count, ems_frame_result *res);
-    /* sum v[] over all devices; called once per round by every device thread, all of them with the same round */
+    /* sum v[] over all devices; called once per round by every device thread, all of them with the same round.  Synchronous form;
+     * used when allreduce_begin is NULL */
     int (*allreduce)(void *ctx, int dev, long long v[EMS_NCOUNTERS]);
     /* the progress line, called in frame order by device 0's thread (may be NULL) */
     void (*line)(const ems_counters *run, void *ctx);
     void *ctx;
+    /* split form (both or neither): begin issues the all-reduce of v[] without waiting for it, end waits for the one begun last and
+     * returns the sums in v[].  At most one is outstanding per device. */
+    int (*allreduce_begin)(void *ctx, int dev, const long long v[EMS_NCOUNTERS]);
+    int (*allreduce_end)(void *ctx, int dev, long long v[EMS_NCOUNTERS]);
 } ems_multi_ops;
 
 typedef struct {
@@ -57,7 +73,8 @@ static void *ems_multi_worker(void *argp)
     ems_counters total;                                   /* running sum of the all-reduced counters: identical on every device */
     memset(&total, 0, sizeof total);
     long long first;
-    int cnt_cur = 0, cnt_next = 0, err = 0;
+    int cnt_cur = 0, cnt_next = 0, err = 0, pending = 0;
+    const int lagged = ops->allreduce_begin != NULL && ops->allreduce_end != NULL;
     ems_round_batch(st->n_frames, st->batch, ndev, 0, dev, &first, &cnt_cur);
     if (cnt_cur > 0 && ops->launch(ops->ctx, dev, 0, first, cnt_cur)) err = 1;
     for (long long r = 0; r < rounds; r++) {
@@ -71,8 +88,20 @@ static void *ems_multi_worker(void *argp)
         long long v[EMS_NCOUNTERS];
         ems_batch_counters(st->res[dev], err ? 0 : cnt_cur, v);
         if (err) st->failed = 1;
-        if (ops->allreduce(ops->ctx, dev, v)) { st->failed = 1; err = 1; }    /* (every thread still reaches the barriers below) */
-        for (int i = 0; i < EMS_NCOUNTERS; i++) total.c[i] += v[i];
+        if (lagged) {
+            /* the all-reduce of round r - 1, issued a round ago, is waited for now that round r has been collected; then this round's
+             * goes out.  (Every thread reaches both calls every round, whatever failed: its peers are inside the same collective.) */
+            if (pending) {
+                long long w[EMS_NCOUNTERS];
+                if (ops->allreduce_end(ops->ctx, dev, w)) { st->failed = 1; err = 1; memset(w, 0, sizeof w); }
+                for (int i = 0; i < EMS_NCOUNTERS; i++) total.c[i] += w[i];
+            }
+            if (ops->allreduce_begin(ops->ctx, dev, v)) { st->failed = 1; err = 1; }
+            pending = 1;
+        } else {
+            if (ops->allreduce(ops->ctx, dev, v)) { st->failed = 1; err = 1; }    /* (every thread still reaches the barriers below) */
+            for (int i = 0; i < EMS_NCOUNTERS; i++) total.c[i] += v[i];
+        }
         st->count[dev] = err ? 0 : cnt_cur;
         pthread_barrier_wait(&st->bar);                   /* every device's results of the round are in place */
         /* The failure flag is LATCHED here, between the two barriers: every write of round r happened before the first barrier and
@@ -80,7 +109,7 @@ static void *ems_multi_worker(void *argp)
          * after the second barrier, a fast thread already failing in round r + 1 could make a slow one leave at r while the fast
          * one waits for it in r + 1's all-reduce or barrier for ever.) */
         const int failed_now = st->failed;
-        if (dev == 0 && !failed_now)
+        if (dev == 0 && !failed_now && !st->truncated)        /* (lagged stop: a round behind the truncation is never tallied) */
             st->truncated = ems_tally_round(&st->run, (const ems_frame_result *const *)st->res, st->count, ndev, st->max_err, ops->line, ops->ctx);
         pthread_barrier_wait(&st->bar);                   /* the tally has read them */
         const int stop = failed_now || ems_global_stop(&total, st->n_frames, st->max_err);
@@ -89,6 +118,10 @@ static void *ems_multi_worker(void *argp)
             break;
         }
         cnt_cur = cnt_next;
+    }
+    if (pending) {                                        /* nothing is left outstanding on the collective's stream */
+        long long w[EMS_NCOUNTERS];
+        if (ops->allreduce_end(ops->ctx, dev, w)) st->failed = 1;
     }
     return NULL;
 }

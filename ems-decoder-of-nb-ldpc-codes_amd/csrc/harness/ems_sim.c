@@ -134,6 +134,7 @@ typedef struct {
     void *comm;                             /* ncclComm_t */
     hipStream_t cstream;                    /* the all-reduce's own stream */
     long long *d_cnt;                       /* [2][5] send | receive */
+    long long *h_cnt;                       /* [2][5] pinned host staging of the same (an asynchronous copy to pageable memory would wait) */
 } dev_ctx;
 
 typedef struct {
@@ -146,6 +147,9 @@ typedef struct {
     long long first_frame;
     double allreduce_timeout_s;             /* watchdog of the per-round all-reduce (EMS_ALLREDUCE_TIMEOUT) */
     rccl_api nccl;
+    int host_sum;                           /* EMS_ALLREDUCE=host: the five counters summed in host memory under a barrier (no RCCL) */
+    pthread_barrier_t hbar;
+    long long (*hslot)[EMS_NCOUNTERS];      /* [ndev] */
 } multi_ctx;
 
 static int m_launch(void *c, int dev, int slot, long long first, int count)
@@ -200,19 +204,31 @@ static void m_allreduce_fatal(const dev_ctx *d, const char *what, const char *de
     _exit(EXIT_FAILURE);                  /* (not exit(): atexit handlers of RCCL / HIP could wait for the stuck collective) */
 }
 
-static int m_allreduce(void *c, int dev, long long v[EMS_NCOUNTERS])
+/* Issued right after a round is collected, waited for one round later (ems_multi.h: the collective's kernel needs a CU, and the next
+ * round's persistent decode workgroups may hold all of them until that round ends). */
+static int m_allreduce_begin(void *c, int dev, const long long v[EMS_NCOUNTERS])
 {
     multi_ctx *m = (multi_ctx *)c;
     dev_ctx *d = &m->d[dev];
     int nrc;
     hipError_t he;
     if ((he = hipSetDevice(d->hip_dev)) != hipSuccess) m_allreduce_fatal(d, "hipSetDevice", hipGetErrorString(he));
-    if ((he = hipMemcpyAsync(d->d_cnt, v, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyHostToDevice, d->cstream)) != hipSuccess)
+    memcpy(d->h_cnt, v, sizeof(long long) * EMS_NCOUNTERS);
+    if ((he = hipMemcpyAsync(d->d_cnt, d->h_cnt, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyHostToDevice, d->cstream)) != hipSuccess)
         m_allreduce_fatal(d, "staging copy", hipGetErrorString(he));
     if ((nrc = m->nccl.AllReduce(d->d_cnt, d->d_cnt + EMS_NCOUNTERS, EMS_NCOUNTERS, RCCL_INT64, RCCL_SUM, d->comm, d->cstream)))
         m_allreduce_fatal(d, "ncclAllReduce", m->nccl.GetErrorString(nrc));
-    if ((he = hipMemcpyAsync(v, d->d_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyDeviceToHost, d->cstream)) != hipSuccess)
+    if ((he = hipMemcpyAsync(d->h_cnt + EMS_NCOUNTERS, d->d_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS, hipMemcpyDeviceToHost, d->cstream)) != hipSuccess)
         m_allreduce_fatal(d, "result copy", hipGetErrorString(he));
+    return 0;
+}
+
+static int m_allreduce_end(void *c, int dev, long long v[EMS_NCOUNTERS])
+{
+    multi_ctx *m = (multi_ctx *)c;
+    dev_ctx *d = &m->d[dev];
+    hipError_t he;
+    if ((he = hipSetDevice(d->hip_dev)) != hipSuccess) m_allreduce_fatal(d, "hipSetDevice", hipGetErrorString(he));
     /* watchdog: poll instead of hipStreamSynchronize, which has no deadline */
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -228,6 +244,22 @@ static int m_allreduce(void *c, int dev, long long v[EMS_NCOUNTERS])
             m_allreduce_fatal(d, "all-reduce watchdog", msg);
         }
     }
+    memcpy(v, d->h_cnt + EMS_NCOUNTERS, sizeof(long long) * EMS_NCOUNTERS);
+    return 0;
+}
+
+/* EMS_ALLREDUCE=host: the device threads of this one process sum the five counters in host memory (synchronous form of ems_multi.h) */
+static int m_allreduce_host(void *c, int dev, long long v[EMS_NCOUNTERS])
+{
+    multi_ctx *m = (multi_ctx *)c;
+    memcpy(m->hslot[dev], v, sizeof m->hslot[dev]);
+    pthread_barrier_wait(&m->hbar);
+    for (int i = 0; i < EMS_NCOUNTERS; i++) {
+        long long sum = 0;
+        for (int k = 0; k < m->ndev; k++) sum += m->hslot[k][i];
+        v[i] = sum;
+    }
+    pthread_barrier_wait(&m->hbar);                                  /* (the slots are free for the next round) */
     return 0;
 }
 
@@ -268,7 +300,8 @@ static int run_multi(const char *devlist, code_t *code, table_t *table, const em
     if (nd < 1) { fprintf(stderr, "EMS_DEVICES=%s: no device\n", devlist); exit(EXIT_FAILURE); }
     multi_ctx m;
     memset(&m, 0, sizeof m);
-    if (rccl_load(&m.nccl)) exit(EXIT_FAILURE);
+    m.host_sum = getenv("EMS_ALLREDUCE") && strcmp(getenv("EMS_ALLREDUCE"), "host") == 0;
+    if (!m.host_sum && rccl_load(&m.nccl)) exit(EXIT_FAILURE);
     m.ndev = nd; m.code = code; m.table = table; m.EbN = EbN; m.gpu_source = gpu_source; m.gpu_seed = gpu_seed; m.first_frame = first_frame;
     m.K = code->K; m.logGF = code->logGF;
     m.allreduce_timeout_s = getenv("EMS_ALLREDUCE_TIMEOUT") ? atof(getenv("EMS_ALLREDUCE_TIMEOUT")) : 120.0;
@@ -283,7 +316,10 @@ static int run_multi(const char *devlist, code_t *code, table_t *table, const em
     m.d = calloc((size_t)nd, sizeof *m.d);
     void **comms = calloc((size_t)nd, sizeof *comms);
     int nrc;
-    if ((nrc = m.nccl.CommInitAll(comms, nd, devs))) {                  /* one communicator per device, this process */
+    if (m.host_sum) {
+        m.hslot = calloc((size_t)nd, sizeof *m.hslot);
+        if (!m.hslot || pthread_barrier_init(&m.hbar, NULL, (unsigned)nd)) { fprintf(stderr, "cannot set up the host-side sum\n"); exit(EXIT_FAILURE); }
+    } else if ((nrc = m.nccl.CommInitAll(comms, nd, devs))) {           /* one communicator per device, this process */
         fprintf(stderr, "ncclCommInitAll(%d devices): %s\n", nd, m.nccl.GetErrorString(nrc));
         exit(EXIT_FAILURE);
     }
@@ -299,25 +335,30 @@ static int run_multi(const char *devlist, code_t *code, table_t *table, const em
         }
         d->iters = malloc(sizeof(int) * batch); d->synd = malloc(sizeof(int) * batch); d->nberr = malloc(sizeof(int) * batch);
         if (hipSetDevice(devs[i]) != hipSuccess || create_collective_stream(&d->cstream) != hipSuccess ||
-            hipMalloc((void **)&d->d_cnt, sizeof(long long) * 2 * EMS_NCOUNTERS) != hipSuccess) {
+            hipMalloc((void **)&d->d_cnt, sizeof(long long) * 2 * EMS_NCOUNTERS) != hipSuccess ||
+            hipHostMalloc((void **)&d->h_cnt, sizeof(long long) * 2 * EMS_NCOUNTERS, hipHostMallocDefault) != hipSuccess) {
             fprintf(stderr, "device %d: cannot set up the all-reduce buffers\n", devs[i]);
             exit(EXIT_FAILURE);
         }
     }
-    fprintf(stderr, "[ems_sim] %d device(s) [%s], one RCCL all-reduce of %d int64 counters per round, batch %d frames per device and round, %d generator thread(s) per device\n",
-            nd, devlist, EMS_NCOUNTERS, batch, m.threads_per_dev);
-    const ems_multi_ops ops = {m_launch, m_collect, m_allreduce, m_line, &m};
+    fprintf(stderr, "[ems_sim] %d device(s) [%s], one %s of %d int64 counters per round, batch %d frames per device and round, %d generator thread(s) per device\n",
+            nd, devlist, m.host_sum ? "host-side sum (EMS_ALLREDUCE=host)" : "RCCL all-reduce (issued when a round is collected, waited for a round later)",
+            EMS_NCOUNTERS, batch, m.threads_per_dev);
+    const ems_multi_ops ops = {m_launch, m_collect, m.host_sum ? m_allreduce_host : NULL, m_line, &m, m.host_sum ? NULL : m_allreduce_begin,
+                               m.host_sum ? NULL : m_allreduce_end};
     if (ems_multi_run(&ops, nd, n_frames, batch, 40, fin)) { fprintf(stderr, "\nmulti-device run failed\n"); exit(EXIT_FAILURE); }
     for (int i = 0; i < nd; i++) {
         dev_ctx *d = &m.d[i];
         (void)hipSetDevice(d->hip_dev);
         (void)hipStreamSynchronize(d->cstream);
-        (void)m.nccl.CommDestroy(d->comm);
+        if (!m.host_sum) (void)m.nccl.CommDestroy(d->comm);
         (void)hipFree(d->d_cnt);
+        (void)hipHostFree(d->h_cnt);
         (void)hipStreamDestroy(d->cstream);
         for (int s = 0; s < 2; s++) { ems_destroy(d->h[s]); free(d->cw[s]); free(d->noisy[s]); }
         free(d->iters); free(d->synd); free(d->nberr);
     }
+    if (m.host_sum) { pthread_barrier_destroy(&m.hbar); free(m.hslot); }
     free(m.d); free(comms);
     return 0;
 }

@@ -21,7 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)          // (the other branch is the HOST compile of tests/ctest/test_q16t.cpp with g++)
 #define Q16T_HD __host__ __device__ __forceinline__
 #else
 #define Q16T_HD inline

@@ -14,6 +14,7 @@
 
 #include "../../include/ems_abi.h"
 #include "../../include/nbldpc_ref_api.h"
+#include "ems_constellations.h"
 
 namespace {
 
@@ -450,6 +451,125 @@ void ModelChannelLLR(code_t *code, decoder_t *decoder, const float *obs, const f
         complain("ModelChannelLLR", rc);
         exit(EXIT_FAILURE); // void signature, as ModelChannel_AWGN_BPSK: never continue on stale LLRs
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The reference's other channel front ends (channel.h:20-26) under their own names, so that a harness which
+// calls them (NB_LDPC.c:262-264, commented out in the reference's main()) links against this library alone.  As with
+// ModelChannel_AWGN_BPSK the split is: constellation construction and the draws on the host, in the reference's drand48 order and with
+// its float / double promotions (every observation is what the reference's NoisyBin holds), the q-wide LLR rows and their ascending
+// sort on the GPU (ModelChannelLLR above -> k_llr_const).  The switches are those the reference ships (channel.c:20-26): rotated QAM,
+// independent Rayleigh fading per axis (rayleigh_fading_SSD), erasures.  Raw constellation data: ems_constellations.h.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr double CH_PI = 3.1415926536;                                   /* channel.c:18 */
+
+// channel.c:206-221 / :565-577 / :791-810: scale so that the average energy per two dimensions is one (float running sum in the
+// reference's association, the square root in double, the product in float)
+void normalise_constellation(std::vector<float> &t, int q, int D)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < q; ++i) {
+        const float *p = &t[(size_t)i * D];
+        acc = p[0] * p[0] + p[1] * p[1] + acc;
+        if (D == 4) acc = p[2] * p[2] + p[3] * p[3] + acc;
+    }
+    const float scale = (float)sqrt((double)((float)((D == 4 ? 2 : 1) * q) / acc));
+    for (float &x : t) x = scale * x;
+}
+
+// channel.c:346-358 / :404-416 / :524-538: the DVB-T2 QAM mapping turned by alpha = 31.7 degrees (alpha is a float, cos / sin in double)
+void rotated_qam(const float *qam, int q, std::vector<float> &t)
+{
+    const float alpha = (float)(31.7 * CH_PI / 180);
+    t.assign((size_t)q * 2, 0.0f);
+    for (int i = 0; i < q; ++i) {
+        const double x = (double)qam[2 * i], y = (double)qam[2 * i + 1];
+        t[2 * i] = (float)(x * cos((double)alpha) - y * sin((double)alpha));
+        t[2 * i + 1] = (float)(y * cos((double)alpha) + x * sin((double)alpha));
+    }
+}
+
+enum ChannelDraw { DRAW_AWGN, DRAW_FADING_ERASURE, DRAW_FADING_RAW_THEN_ERASURE };
+
+// One frame's observations and attenuations, [N][D] flat.  Per node the binary image of its symbol (`som`, channel.c:249-252), per axis
+// the uniforms u, v of the Box-Muller sample (channel.c:255-261 / :636-640 / :831-833); with fading a third uniform for the attenuation
+// sqrt(-log w) and a fourth for the erasure (probability 0.1: attenuation 0, else rescaled by 1 / sqrt(0.9); channel.c:648-669).
+// ModelChannel forms the observation with the erased / rescaled attenuation (:674), the 4-D front end with the raw one and only
+// STORES the erased one for the LLR (:836-860) -- kept as it is.
+void draw_observations(ChannelDraw kind, const std::vector<float> &table, int D, code_t *code, int **NBIN, float sigma, int *init_rand,
+                       std::vector<float> &obs, std::vector<float> &att)
+{
+    const float erasure_proba = (float)0.1;                              /* channel.c:593 / :771 */
+    const int N = code->N;
+    obs.assign((size_t)N * D, 0.0f);
+    att.assign((size_t)N * D, 1.0f);
+    for (int n = 0; n < N; ++n) {
+        int image = 0;
+        for (int l = 0; l < code->logGF; ++l) image += NBIN[n][l] << l;
+        for (int d = 0; d < D; ++d) {
+            const float u = My_drand48(init_rand);
+            const float v = My_drand48(init_rand);
+            const double noise = (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * CH_PI * (double)v);
+            const float point = table[(size_t)image * D + d];
+            float a = 1.0f;
+            if (kind == DRAW_AWGN) {
+                obs[(size_t)n * D + d] = (float)((double)point + noise);
+            } else {
+                a = (float)sqrt(-log((double)My_drand48(init_rand)));
+                const float raw = a;
+                a = My_drand48(init_rand) < erasure_proba ? 0.0f : (float)((double)a / sqrt((double)(1 - erasure_proba)));
+                obs[(size_t)n * D + d] = (float)((double)(point * (kind == DRAW_FADING_RAW_THEN_ERASURE ? raw : a)) + noise);
+            }
+            att[(size_t)n * D + d] = a;
+        }
+    }
+}
+
+float snr_sigma(float EbN) { return (float)sqrt(1.0 / (2.0 * pow(10, (double)EbN / 10.0))); }   /* channel.c:233 / :596 / :812: no code rate here */
+} // namespace
+
+void ModelChannel_AWGN_64(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand)      /* channel.c:112-310 */
+{
+    if (code->GF != 64) { fprintf(stderr, "ModelChannel_AWGN_64: the 64-APSK front end needs GF(64), not GF(%d)\n", code->GF); exit(EXIT_FAILURE); }
+    std::vector<float> table(64 * 2), obs, att;
+    for (int i = 0; i < 64; ++i) {                                       /* :132-199: double radius * cos / sin, stored as float */
+        table[2 * i] = (float)(kApsk64Radius[i] * cos(CH_PI * kApsk64Num[i] / kApsk64Den[i]));
+        table[2 * i + 1] = (float)(kApsk64Radius[i] * sin(CH_PI * kApsk64Num[i] / kApsk64Den[i]));
+    }
+    normalise_constellation(table, 64, 2);
+    const float sigma = snr_sigma(EbN);
+    draw_observations(DRAW_AWGN, table, 2, code, NBIN, sigma, init_rand, obs, att);
+    ModelChannelLLR(code, decoder, obs.data(), nullptr, table.data(), 2, EMS_LLR_SUM, sigma);             /* :270-304 */
+}
+
+void ModelChannel(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand)             /* channel.c:328-736 */
+{
+    const int q = code->GF;
+    if (q != 16 && q != 64 && q != 256) { fprintf(stderr, "ModelChannel: GF(%d) has no constellation (16, 64, 256)\n", q); exit(EXIT_FAILURE); }
+    std::vector<float> table, obs, att;
+    rotated_qam(q == 256 ? kQam256 : (q == 64 ? kQam64 : kQam16), q, table);
+    normalise_constellation(table, q, 2);
+    const float sigma = snr_sigma(EbN);
+    draw_observations(DRAW_FADING_ERASURE, table, 2, code, NBIN, sigma, init_rand, obs, att);
+    ModelChannelLLR(code, decoder, obs.data(), att.data(), table.data(), 2, EMS_LLR_SSD, sigma);          /* :676-730 */
+}
+
+void ModelChannel_AWGN_256QAM_4D(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand)   /* channel.c:749-929 */
+{
+    if (code->GF != 256) { fprintf(stderr, "ModelChannel_AWGN_256QAM_4D: needs GF(256), not GF(%d)\n", code->GF); exit(EXIT_FAILURE); }
+    std::vector<float> table(kQam4d16R, kQam4d16R + 256 * 4), obs, att;                                   /* :784-787 */
+    normalise_constellation(table, 256, 4);
+    const float sigma = snr_sigma(EbN);
+    draw_observations(DRAW_FADING_RAW_THEN_ERASURE, table, 4, code, NBIN, sigma, init_rand, obs, att);
+    ModelChannelLLR(code, decoder, obs.data(), att.data(), table.data(), 4, EMS_LLR_SSD, sigma);          /* :861-915 */
+}
+
+void build_QAM_table(int logGF)                                          /* channel.c:931-942: prints the half-integer grid of a square QAM */
+{
+    const int half = 1 << ((logGF >> 1) - 1);
+    for (int i = -half; i < half; ++i)
+        for (int j = -half; j < half; ++j) printf("%f \t %f \n", i + 0.5, j + 0.5);
 }
 
 // ---------------------------------------------------------------------------------------------------

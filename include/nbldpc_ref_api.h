@@ -109,6 +109,16 @@ void ModelChannel_AWGN_BPSK(code_t *code, decoder_t *decoder, table_t *table, in
 void ModelChannelLLR(code_t *code, decoder_t *decoder, const float *obs, const float *att, const float *table, int D,
                      int mode, float sigma);
 
+/* ---- channel.h:20-26 (round 5): the reference's other channel front ends under their own names -- the calls NB_LDPC.c:262-264 keeps
+ *      commented out next to ModelChannel_AWGN_BPSK.  Constellation construction and the draws on the host (the reference's drand48
+ *      order and promotions, channel.c:112-266 / :328-680 / :749-860, as its shipped switches channel.c:20-26 compile them: rotated QAM,
+ *      independent Rayleigh fading per axis, erasures), LLR rows + ascending sort on the GPU through ModelChannelLLR.  GF(64) /
+ *      GF(16, 64, 256) / GF(256); anything else ends the process with a message, as the void signatures leave no other way. ---- */
+void ModelChannel_AWGN_64(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand);        /* channel.h:20 */
+void ModelChannel(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand);                /* channel.h:22 */
+void ModelChannel_AWGN_256QAM_4D(code_t *code, decoder_t *decoder, int **NBIN, float EbN, int *init_rand); /* channel.h:24 */
+void build_QAM_table(int logGF);                                                                           /* channel.h:26 (prints a grid) */
+
 /* ---- bubble_decoder.h:15-17,26 ---- */
 int maximum(float *Y, int nl);                                                             /* host helper */
 int minimum(float *Y, int nl);                                                             /* host helper */

@@ -6,7 +6,11 @@
  * to the sequential tally.
  * Failure injection: three more arguments <device> <launch|collect> <k> make that device's k-th call (0-based) of that callback fail.
  * The loop must then END on every thread -- nobody left in a barrier or in the all-reduce -- and ems_multi_run must return -1:
- * exit code 4.  (A hang shows as the caller's timeout.) */
+ * exit code 4.  (A hang shows as the caller's timeout.)
+ * EMS_TALLY_LAGGED=1 in the environment: the split all-reduce of ems_multi.h (allreduce_begin / allreduce_end: issued when a round is
+ * collected, waited for one round later) instead of the synchronous one.  Every callback is then logged per device and the ORDER is
+ * asserted: launch(r+1) < collect(r) < [end(r-1)] < begin(r), i.e. the all-reduce of round r is never waited for before round r+1 has been
+ * collected, and none is outstanding when the run ends. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,13 +48,23 @@ typedef struct {
     char *trace; size_t len, cap;
     int launches, drains;
     pthread_mutex_t mu;
+    long long pend[64][EMS_NCOUNTERS];            /* split form: what begin() left for end() */
+    int outstanding[64];
+    char *ev[64]; size_t evn[64], evcap[64];     /* per-device event log: 'L' launch, 'C' collect, 'D' drain, 'B' begin, 'E' end */
 } fake_ctx;
+
+static void logev(fake_ctx *x, int dev, char e)
+{
+    if (x->evn[dev] + 1 > x->evcap[dev]) { x->evcap[dev] = 2 * x->evcap[dev] + 256; x->ev[dev] = (char *)realloc(x->ev[dev], x->evcap[dev]); }
+    x->ev[dev][x->evn[dev]++] = e;
+}
 
 static int f_launch(void *c, int dev, int slot, long long first, int count)
 {
     fake_ctx *x = (fake_ctx *)c;
     if (dev == g_fail_dev && g_fail_kind == 1 && g_calls[dev][1]++ == g_fail_at) return -1;
     x->first[dev][slot] = first; x->count[dev][slot] = count;
+    logev(x, dev, 'L');
     pthread_mutex_lock(&x->mu); x->launches++; pthread_mutex_unlock(&x->mu);
     return 0;
 }
@@ -59,7 +73,8 @@ static int f_collect(void *c, int dev, int slot, int count, ems_frame_result *re
     fake_ctx *x = (fake_ctx *)c;
     if (count != x->count[dev][slot]) return -1;
     if (dev == g_fail_dev && g_fail_kind == 2 && res && g_calls[dev][2]++ == g_fail_at) return -1;
-    if (!res) { pthread_mutex_lock(&x->mu); x->drains++; pthread_mutex_unlock(&x->mu); return 0; }
+    if (!res) { logev(x, dev, 'D'); pthread_mutex_lock(&x->mu); x->drains++; pthread_mutex_unlock(&x->mu); return 0; }
+    logev(x, dev, 'C');
     for (int b = 0; b < count; b++) res[b] = fake_result(x->first[dev][slot] + b);
     return 0;
 }
@@ -75,6 +90,44 @@ static int f_allreduce(void *c, int dev, long long v[EMS_NCOUNTERS])
         x->seen_total[dev][i] += s;
     }
     pthread_barrier_wait(&x->bar);
+    return 0;
+}
+/* split form: begin only deposits the contribution (nothing may wait in it), end meets the other devices */
+static int f_begin(void *c, int dev, const long long v[EMS_NCOUNTERS])
+{
+    fake_ctx *x = (fake_ctx *)c;
+    if (x->outstanding[dev]) return -1;                         /* at most one outstanding per device */
+    memcpy(x->pend[dev], v, sizeof x->pend[dev]);
+    x->outstanding[dev] = 1;
+    logev(x, dev, 'B');
+    return 0;
+}
+static int f_end(void *c, int dev, long long v[EMS_NCOUNTERS])
+{
+    fake_ctx *x = (fake_ctx *)c;
+    if (!x->outstanding[dev]) return -1;
+    logev(x, dev, 'E');
+    memcpy(v, x->pend[dev], sizeof x->pend[dev]);
+    x->outstanding[dev] = 0;
+    return f_allreduce(c, dev, v);
+}
+/* the order ems_multi.h promises for the split form, on one device's log: (L) then per round [L] C [E] B, drains and the last E at the end */
+static int order_ok(const char *ev, size_t n)
+{
+    size_t i = 0;
+    int round = 0;
+    if (n == 0) return 1;
+    if (ev[i] == 'L') i++;                                      /* round 0 goes out */
+    while (i < n) {
+        if (ev[i] == 'L') i++;                                  /* launch(r+1) BEFORE collect(r) */
+        if (i < n && ev[i] == 'C') i++;                         /* (a device whose stream has run out has nothing to collect) */
+        if (round > 0) { if (i >= n || ev[i] != 'E') return 0; i++; }   /* end(r-1) only now: round r has been collected */
+        if (i >= n || ev[i] != 'B') return 0;
+        i++;
+        round++;
+        if (i < n && ev[i] == 'D') i++;                         /* dropped round at the stop */
+        if (i + 1 == n && ev[i] == 'E') return 1;               /* the last all-reduce is waited for when the loop is left */
+    }
     return 0;
 }
 static void f_line(const ems_counters *run, void *c)
@@ -105,11 +158,13 @@ int main(int argc, char **argv)
     x.ndev = ndev;
     pthread_barrier_init(&x.bar, NULL, (unsigned)ndev);
     pthread_mutex_init(&x.mu, NULL);
-    ems_multi_ops ops = {f_launch, f_collect, f_allreduce, f_line, &x};
+    const int lagged = getenv("EMS_TALLY_LAGGED") != NULL;
+    ems_multi_ops ops = {f_launch, f_collect, lagged ? NULL : f_allreduce, f_line, &x, lagged ? f_begin : NULL, lagged ? f_end : NULL};
     ems_counters fin;
     if (ems_multi_run(&ops, ndev, n_frames, batch, 40, &fin)) {
         fprintf(stderr, "ems_multi_run failed%s\n", g_fail_dev >= 0 ? " (as injected): every device thread came back" : "");
         free(x.trace);
+        for (int d = 0; d < ndev; d++) free(x.ev[d]);
         return g_fail_dev >= 0 ? 4 : 3;
     }
 
@@ -129,6 +184,14 @@ int main(int argc, char **argv)
     /* the all-reduced totals cover whole rounds: at least the ordered tally, and equal to it when the run was not truncated */
     ok = ok && x.seen_total[0][EMS_CNT_FRAMES] >= fin.c[EMS_CNT_FRAMES] && x.seen_total[0][EMS_CNT_ERR_FRAMES] >= fin.c[EMS_CNT_ERR_FRAMES];
     if (fin.c[EMS_CNT_ERR_FRAMES] < 40) ok = ok && memcmp(x.seen_total[0], fin.c, sizeof fin.c) == 0 && fin.c[EMS_CNT_FRAMES] == n_frames;
+    if (lagged)
+        for (int d = 0; d < ndev; d++) {
+            if (!order_ok(x.ev[d], x.evn[d]) || x.outstanding[d]) {
+                fprintf(stderr, "device %d: callback order %.*s breaks launch(r+1) < collect(r) < end(r-1) < begin(r)\n", d, (int)x.evn[d], x.ev[d]);
+                ok = 0;
+            }
+        }
+    for (int d = 0; d < ndev; d++) free(x.ev[d]);
     fprintf(stderr, "ndev %d batch %d: %lld frames tallied, %lld erroneous, %d launches, %d dropped -> %s\n", ndev, batch, fin.c[EMS_CNT_FRAMES],
             fin.c[EMS_CNT_ERR_FRAMES], x.launches, x.drains, ok ? "EQUAL to the sequential tally" : "MISMATCH");
     free(x.trace); free(y.trace);

@@ -90,6 +90,15 @@ def kat_traces():
         "R1": ("ubs", "LOCAL/Rep_N40_M20_GF64", 60, 10, 3.0, 12, 0.3, 24),
         "R2": ("ubs", "LOCAL/Rep_N40_M20_GF64", 40, 6, 6.0, 16, 0.5, 32),
         "R3": ("ubs", "LOCAL/RepWide_N54_M6_GF64", 60, 8, 5.0, 16, 0.3, 32),     # check degree 18: repeats inside and across the passes of k_decode_wide
+        # the reference's main() with one of its OTHER channel front ends switched in (NB_LDPC.c:262-264 un-commented instead of the BPSK call
+        # of line 261; oracle/Makefile builds these executables as essai_ubs_apsk / _qam / _4d): ModelChannel_AWGN_64 (64-APSK), ModelChannel
+        # (rotated QAM, fading and erasures per axis, as channel.c:20-26 ships it) over GF(64) / GF(256) / GF(16), ModelChannel_AWGN_256QAM_4D.
+        # EbN is an SNR here (channel.c:233 / :596 / :812 drop the code rate)
+        "Q1": ("ubs_apsk", "N96_K48_GF64", 150, 10, 12.0, 16, 0.3, 32),
+        "Q2": ("ubs_qam", "N96_K48_GF64", 150, 10, 16.0, 16, 0.3, 32),
+        "Q3": ("ubs_qam", "LOCAL/Irr345_N60_M24_GF256", 100, 10, 28.0, 16, 0.5, 32),
+        "Q4": ("ubs_qam", "LOCAL/Wide_N120_M6_GF16", 150, 10, 20.0, 8, 0.3, 16),
+        "Q5": ("ubs_4d", "LOCAL/Irr345_N60_M24_GF256", 100, 10, 16.0, 16, 0.5, 32),
     }
     dst = os.path.join(HERE, "kat_traces.json")
     out = json.load(open(dst)) if os.path.exists(dst) and os.environ.get("KAT_KEEP", "1") == "1" else {}
@@ -99,8 +108,10 @@ def kat_traces():
         path = os.path.join(HERE, "matrices", mat[6:]) if mat.startswith("LOCAL/") else REFM + mat
         tr = orc.run_reference_binary(fmt, nf, it, path, eb, nm, off, nop)
         assert len(tr) == nf or tr[-1][0] == 40, (k, len(tr))          # (all frames, or the 40-error stop of NB_LDPC.c:506)
-        out[k] = {"matrix": os.path.basename(mat), "fmt": fmt, "frames": nf, "NbIterMax": it, "EbN": eb, "nm": nm,
+        out[k] = {"matrix": os.path.basename(mat), "fmt": fmt.split("_")[0], "frames": nf, "NbIterMax": it, "EbN": eb, "nm": nm,
                   "offset": off, "NbOper": nop, "trace": tr}
+        if "_" in fmt:
+            out[k]["chan"] = fmt.split("_", 1)[1]       # which channel call of NB_LDPC.c:262-264 was switched in
         print(k, tr[-1], flush=True)
     json.dump(out, open(os.path.join(HERE, "kat_traces.json"), "w"), indent=0)
 

@@ -43,6 +43,22 @@ def test_reference_main_links_against_the_library(pkg):
     assert wanted <= _dynamic_symbols(pkg.LIB_PATH, False)
 
 
+CHAN_SYMBOL = {"apsk": "ModelChannel_AWGN_64", "qam": "ModelChannel", "4d": "ModelChannel_AWGN_256QAM_4D"}
+
+
+@pytest.mark.parametrize("chan", ["apsk", "qam", "4d"])
+def test_reference_main_with_another_channel_links_against_the_library_alone(pkg, chan):
+    """NB_LDPC.c with line 262 / 263 / 264 un-commented instead of the BPSK call (oracle/Makefile: essai_gpu_apsk / _qam / _4d): the library
+    exports the reference's other channel front ends under their own names (channel.h:20-26), so nothing but libems_hip.so is linked."""
+    exe = ESSAI_GPU + "_" + chan
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/essai_gpu_%s is not built (make -C oracle ref, needs /root/reference)" % chan)
+    wanted = {s for s in _dynamic_symbols(exe, True) if not s.startswith("_") and s[0].isupper()}
+    assert CHAN_SYMBOL[chan] in wanted and "ModelChannel_AWGN_BPSK" not in wanted and "Decoding" in wanted
+    assert wanted <= _dynamic_symbols(pkg.LIB_PATH, False)
+    assert "build_QAM_table" in _dynamic_symbols(pkg.LIB_PATH, False)                     # channel.h:26
+
+
 def _run(exe, args, cwd):
     os.makedirs(os.path.join(cwd, "data"), exist_ok=True)
     out = subprocess.run([exe] + [str(a) for a in args], cwd=cwd, input=b"\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -61,6 +77,21 @@ def test_reference_main_on_the_gpu_library_prints_the_reference_traces(kat, tmp_
     k = kat[name]
     matrix = ("KN_" + k["matrix"]) if k.get("fmt") == "kn" and not k["matrix"].startswith("KN_") else k["matrix"]     # (the library's loader detects the layout itself)
     tr = _run(ESSAI_GPU, [k["frames"], k["NbIterMax"], os.path.join(MAT, matrix), k["EbN"], k["nm"], k["offset"], k["NbOper"]], str(tmp_path))
+    assert tr == [list(t) for t in k["trace"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Q1", "Q2", "Q3", "Q4", "Q5"])
+def test_reference_main_with_another_channel_prints_the_reference_traces(kat, tmp_path, name):
+    """The same main() behind ModelChannel_AWGN_64 (64-APSK), ModelChannel (rotated QAM, fading and erasures per axis; GF(64) / GF(256) /
+    GF(16)) and ModelChannel_AWGN_256QAM_4D, all three now exported by the library (host-side draws in the reference's drand48 order, LLR
+    rows + sort on the GPU): the traces of the REAL executable with that call switched in (kat_traces.json Q1..Q5, from
+    oracle/_ref/essai_ubs_apsk / _qam / _4d)."""
+    k = kat[name]
+    exe = ESSAI_GPU + "_" + k["chan"]
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/essai_gpu_%s is not built (make -C oracle ref, needs /root/reference)" % k["chan"])
+    tr = _run(exe, [k["frames"], k["NbIterMax"], os.path.join(MAT, k["matrix"]), k["EbN"], k["nm"], k["offset"], k["NbOper"]], str(tmp_path))
     assert tr == [list(t) for t in k["trace"]]
 
 

@@ -158,3 +158,41 @@ def test_sum_mode_with_fading(orc, chan):
     e0 = (obs[1, 0] - t[:, 0] * a[1]).astype(np.float32); e1 = (obs[1, 1] - a[1] * t[:, 1]).astype(np.float32)
     den = 2.0 * float(np.float32(0.4) * np.float32(0.4))
     assert s0[1].tobytes() == ((e0 * e0).astype(np.float64) / den + (e1 * e1).astype(np.float64) / den).astype(np.float32).tobytes()
+
+
+# ---- whole simulations of the reference's main() behind its other channel front ends (NB_LDPC.c:262-264 switched in; round 5) ----
+KIND_OF_CHAN = {"apsk": "apsk64", "qam": "qamr_ssd", "4d": "qam4d"}
+
+
+def oracle_simulation(orc, chan, k):
+    """The loop of NB_LDPC.c:250-506 in oracle calls: RandomBinaryGenerator, Encoding, the channel's draws and LLR rows, the decode,
+    the bit-error count; returns the cumulative trace the executable prints."""
+    raw = np.load(os.path.join(GOLD, "channel_const.npz"))
+    o = orc.Oracle(os.path.join(MAT, k["matrix"]))
+    ch = chan.Channel(KIND_OF_CHAN[k["chan"]], o.q, raw)
+    L = o.L
+    rng = orc.Rng(0)
+    sigma = ch.sigma(k["EbN"])
+    rec = []
+    errf = 0
+    for _ in range(k["frames"]):
+        ks = np.zeros(o.K, np.int32)
+        cw = np.zeros(o.N, np.int32)
+        L.orc_random_info(C.byref(rng), o.code_p, C.byref(o.gf), ks.ctypes.data_as(C.POINTER(C.c_int)))
+        L.orc_encode(C.c_void_p(o.enc), ks.ctypes.data_as(C.POINTER(C.c_int)), cw.ctypes.data_as(C.POINTER(C.c_int)))
+        obs, att = ch.draw(rng, cw, sigma)
+        res = o.decode(ch.llr(obs, att if ch.mode != chan.MODE_SUM else None, sigma), k["nm"], k["NbOper"], k["offset"], k["NbIterMax"])
+        nb = o.bit_errors(res["decide"], cw)
+        rec.append((nb, res["synd"], res["iters"]))
+        errf += nb != 0
+        if errf == 40:
+            break
+    return [list(t) for t in orc.trace_from_records(np.array(rec, np.int32), o.K, o.logq)]
+
+
+@pytest.mark.parametrize("name", ["Q1", "Q2", "Q3", "Q4", "Q5"])
+def test_oracle_reproduces_the_executables_with_the_other_channels(orc, chan, kat, name):
+    """tests/golden/kat_traces.json Q1..Q5: the REAL executable with ModelChannel_AWGN_64 / ModelChannel / ModelChannel_AWGN_256QAM_4D
+    switched into its main() (oracle/_ref/essai_ubs_apsk / _qam / _4d), frame for frame: draws, LLR rows, decode and counting together."""
+    k = kat[name]
+    assert oracle_simulation(orc, chan, k) == [list(t) for t in k["trace"]]

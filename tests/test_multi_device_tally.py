@@ -31,8 +31,13 @@ def tally_exe(tmp_path_factory):
 
 @pytest.mark.parametrize("ndev,batch,frames,rate", [(1, 7, 500, 30), (2, 64, 5000, 30), (8, 16, 100000, 3), (3, 5, 200, 0), (8, 1536, 20000, 4),
                                                      (5, 1, 300, 200), (4, 100, 250, 1000), (8, 256, 300, 50), (7, 33, 1000, 0), (2, 1, 1, 1000)])
-def test_fake_n_device_run_equals_sequential_tally(tally_exe, ndev, batch, frames, rate):
-    out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), str(rate)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+@pytest.mark.parametrize("lagged", [False, True])
+def test_fake_n_device_run_equals_sequential_tally(tally_exe, ndev, batch, frames, rate, lagged):
+    """lagged: the split all-reduce of ems_multi.h (what ems_sim gives RCCL): issued when a round is collected, waited for a round later, so
+    that a collective kernel queued behind the next round's persistent decode workgroups never stalls the host -- the ctest logs every
+    callback and asserts launch(r+1) < collect(r) < end(r-1) < begin(r) on every device; the trace must not change."""
+    env = dict(os.environ, EMS_TALLY_LAGGED="1") if lagged else {k: v for k, v in os.environ.items() if k != "EMS_TALLY_LAGGED"}
+    out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), str(rate)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = out.stdout.decode().splitlines()
     assert len(lines) <= frames
@@ -43,12 +48,14 @@ def test_fake_n_device_run_equals_sequential_tally(tally_exe, ndev, batch, frame
 
 @pytest.mark.parametrize("ndev,batch,frames,dev,kind,at", [(4, 8, 4000, 2, "launch", 0), (4, 8, 4000, 0, "launch", 3), (8, 16, 100000, 5, "collect", 7),
                                                             (3, 5, 2000, 2, "collect", 0), (2, 64, 5000, 1, "launch", 1), (8, 4, 100000, 7, "launch", 40)])
-def test_a_failing_device_ends_the_run_instead_of_hanging_it(tally_exe, ndev, batch, frames, dev, kind, at):
+@pytest.mark.parametrize("lagged", [False, True])
+def test_a_failing_device_ends_the_run_instead_of_hanging_it(tally_exe, ndev, batch, frames, dev, kind, at, lagged):
     """One device's launch or collect fails in some round while the others are rounds ahead or behind: every thread must take the
     same decision for that round (the failure flag is latched between the round's two barriers) and leave; a thread left waiting
     in the all-reduce or a barrier would show as the timeout here."""
     for _ in range(5):                                           # thread interleavings differ from run to run
-        out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), "3", str(dev), kind, str(at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        env = dict(os.environ, EMS_TALLY_LAGGED="1") if lagged else {k: v for k, v in os.environ.items() if k != "EMS_TALLY_LAGGED"}
+        out = subprocess.run([tally_exe, str(ndev), str(batch), str(frames), "3", str(dev), kind, str(at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
         assert out.returncode == 4, (out.returncode, out.stderr.decode()[-2000:])
 
 
