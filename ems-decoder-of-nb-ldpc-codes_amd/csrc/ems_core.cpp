@@ -1332,6 +1332,20 @@ int ems_v2_decode(ems_handle *h, int B)
             P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
         }
     }
+    if (P.t_dc != nullptr) {
+        // irregular (2, dc) code or check degree above 16: k_decode_v2_wide (edges of a visit in passes, per-visit degrees), as many waves as
+        // the frame's widest level, the kernel's launch bound (8) and the CU's LDS allow
+        P.dual = 0; P.occ4 = 0; P.twin = 0; P.q16t = 0;
+        P.wave_lds_bytes = (int)ems_v2wide_wave_lds_bytes(h->q, h->dc, P.nm);
+        int widest = 1;
+        for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
+        int waves = std::min(8, widest);
+        if (h->tune.waves > 0) waves = std::max(1, std::min(8, h->tune.waves));
+        while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > h->lds_cu) --waves;
+        if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > h->lds_cu)
+            return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d with nm = %d over GF(%d) does not fit the %zu KiB of LDS", h->dc, P.nm, h->q, h->lds_cu / 1024);
+        P.waves_per_wg = waves;
+    }
     P.nsweeps = h->prm.NbIterMax + 1;                                   // iter = 0..NbIterMax inclusive (v2.c:2119)
     P.v2_like = h->d_v2_like.p; P.v2_msg = h->d_v2_msg.p; P.v2_rec = ems_v2_rec_bytes(h->nm_alloc); P.v2_app = h->d_v2_app.p; P.t_dst = h->d_v2_t_dst.p; P.vn_edge = h->d_v2_vn_edge.p; P.t_last = h->d_v2_t_last.p;
     P.v2_cw = nullptr; P.v2_snap = nullptr; P.K = h->K;

@@ -20,7 +20,7 @@ def v2(orc):
     return importlib.import_module("orc_v2")
 
 
-def _check_frames(pkg, v2, mat, q, logq, nm, nop, off, itmax, cases, early_exit=True, full_state=True):
+def _check_frames(pkg, v2, mat, q, logq, nm, nop, off, itmax, cases, early_exit=True, full_state=True, kernel=None):
     path = os.path.join(MAT, mat)
     o = v2.V2Oracle(path)
     pairs = [v2.synthetic_likelihood(o.N, q, logq, o.o.idx2bin, sg, seed) for sg, seed in cases]
@@ -28,6 +28,7 @@ def _check_frames(pkg, v2, mat, q, logq, nm, nop, off, itmax, cases, early_exit=
     idx = np.stack([p[1] for p in pairs])
     dec = pkg.Decoder(pkg.Code(path), nm, nop, off, itmax, max_batch=len(cases), early_exit=early_exit)
     decide, iters, synd = dec.v2_decode_batch(like, idx)
+    assert kernel is None or dec.last_kernel.startswith(kernel), dec.last_kernel
     out = []
     for b in range(len(cases)):
         ref = o.decode(like[b], idx[b], nm, nop, off, itmax, early_exit=early_exit)
@@ -92,6 +93,21 @@ def test_v2_check_degree_12(pkg, v2):
     """dc = 12 (rows of 4 lanes): the rate-5/6 GF(256) code and a small GF(64) one."""
     _check_frames(pkg, v2, "Ahmed_64800_R56_GF256", 256, 8, 20, 40, 0.3, 4, [(0.42, 31)])
     _check_frames(pkg, v2, "Mat212_N96_M16", 64, 6, 12, 24, 0.3, 6, [(0.5, 32), (0.8, 33)])
+
+
+def test_v2_check_degrees_above_16_and_irregular_codes(pkg, v2):
+    """Round 5 (k_decode_v2_wide): the older generation caps the check degree nowhere (v2.c:1756-1852 loops over rowDegree[node], :750 /
+    :794-800 size the scratch by rowDegree[0]).  An irregular (2, dc) code with degrees 2..12, dc = 22 over GF(256), dc = 18 over GF(64)
+    (tests/golden/make_v2_degree_matrices.py) and the reference's own rate-9/10 matrix (dc = 20): every message array against the oracle,
+    which tests/test_v2_oracle_vs_reference.py holds to the REAL functions on the same codes.  Fast and literal elementary steps."""
+    K = "k_decode_v2_wide"
+    _check_frames(pkg, v2, "V2Irr_M24_GF256", 256, 8, 20, 40, 0.3, 8, [(0.55, 41), (0.8, 42), (1.1, 43), (0.65, 48)], kernel=K)
+    _check_frames(pkg, v2, "V2Irr_M24_GF256", 256, 8, 8, 11, 1.0, 5, [(0.7, 44), (0.9, 49)], early_exit=False, kernel=K)
+    _check_frames(pkg, v2, "V2Irr_M24_GF256", 256, 8, 12, 80, 0.5, 6, [(0.7, 50)], kernel=K)            # NbOper > 64: literal elementary steps
+    _check_frames(pkg, v2, "V2Irr_M24_GF256", 256, 8, 36, 40, 0.3, 4, [(0.7, 51)], kernel=K)            # nm > 32: literal steps, literal selection
+    _check_frames(pkg, v2, "V2Wide22_M10_GF256", 256, 8, 20, 40, 0.3, 6, [(0.4, 45), (0.6, 46), (0.5, 52)], kernel=K)
+    _check_frames(pkg, v2, "V2Wide18_M8_GF64", 64, 6, 12, 24, 0.5, 8, [(0.45, 53), (0.6, 54), (0.8, 55)], kernel=K)
+    _check_frames(pkg, v2, "Ahmed_64800_R910_GF256", 256, 8, 20, 40, 0.3, 4, [(0.3, 47), (0.33, 56)], kernel=K)
 
 
 def test_v2_big_code_vs_oracle(pkg, v2):
@@ -245,7 +261,7 @@ def test_v2_snapshots_vs_oracle(pkg, v2, monkeypatch, dual):
     dec.close()
 
 
-@pytest.mark.parametrize("case,batch", [("V1", 24), ("V2", 5), ("V3", 3)])
+@pytest.mark.parametrize("case,batch", [("V1", 24), ("V2", 5), ("V3", 3), ("V4", 8), ("V5", 7), ("V6", 40)])     # V4..V6: dc = 20 (the reference's rate-9/10 matrix), irregular (2, dc), dc = 22
 def test_v2_harness_prints_the_lines_of_the_v2_executable(pkg, tmp_path, case, batch):
     """csrc/harness/ems_sim_v2.c (host draws in the reference's drand48 order, GPU likelihoods + decode + BER samples) against every
     statistics line the REAL EMS_HS_L-BubbleCheck_UBS_decoder_v2.c executable printed (tests/golden/v2_traces.json, generated by
@@ -274,7 +290,8 @@ def test_v2_more_than_255_iterations(pkg, v2, monkeypatch):
 @pytest.mark.parametrize("block", range(int(os.environ.get("EMS_FUZZ_V2_HARNESS", "2"))))
 def test_v2_harness_on_random_codes_equals_the_real_executable(pkg, tmp_path, block):
     """Live on the GPU box: the REAL older-generation executable (oracle/_ref/essai_v2, built from /root/reference where it lies and carried
-    along as a binary) and csrc/harness/ems_sim_v2.c with the same argv on seeded random (2, dc)-regular GF(256) codes -- every statistics
+    along as a binary) and csrc/harness/ems_sim_v2.c with the same argv on seeded random (2, dc) GF(256) codes -- regular with dc 3..24 and (round 5)
+    irregular with the largest degree in row 0 -- every statistics
     line (BER samples at iterations 9 / 19 / 29 / 39 / 49, the "> 12 bit errors" frame rule), frame after frame, at SNRs where frames fail."""
     import re
     import subprocess
@@ -285,18 +302,27 @@ def test_v2_harness_on_random_codes_equals_the_real_executable(pkg, tmp_path, bl
         pytest.skip("oracle/_ref/essai_v2 is not built (make -C oracle ref, needs /root/reference)")
     rs = np.random.RandomState(7700 + block)
     pat = r"<\d+> FER= \d+/ \d+ = \S+ BER= \d+/ \d+ = \S+"
-    for case in range(5):
-        dc = int(rs.choice([3, 4, 6, 8, 12]))
+    for case in range(6):
         M = 2 * int(rs.randint(4, 24))
-        N = M * dc // 2
+        if case < 4:                                             # (2, dc)-regular, lane-row kernels up to 16, k_decode_v2_wide above
+            degs = [int(rs.choice([3, 4, 6, 8, 12, 17, 20, 24]))] * M
+        else:                                                    # irregular (2, dc): the largest degree in row 0, where the executable sizes its scratch
+            top = int(rs.choice([8, 12, 18, 21]))
+            while True:
+                degs = [top] + [int(rs.randint(2, top + 1)) for _ in range(M - 1)]
+                if sum(degs) % 2 == 0:
+                    break
+        N = sum(degs) // 2
         while True:
             slots = [int(c) for c in rs.permutation(np.repeat(np.arange(N), 2))]
-            rows = [slots[m * dc:(m + 1) * dc] for m in range(M)]
-            if all(len(set(r)) == dc for r in rows):
+            rows, k0 = [], 0
+            for d in degs:
+                rows.append(slots[k0:k0 + d]); k0 += d
+            if all(len(set(r)) == len(r) for r in rows):
                 break
-        coefs = [[int(x) for x in rs.randint(1, 256, dc)] for _ in range(M)]
+        coefs = [[int(x) for x in rs.randint(1, 256, d)] for d in degs]
         path = str(tmp_path / ("v2h_%d_%d" % (block, case)))
-        write(path, N, M, 256, [dc] * M, rows, coefs)
+        write(path, N, M, 256, degs, rows, coefs)
         nm = int(rs.choice([8, 12, 20]))
         argv = [str(a) for a in (int(rs.randint(6, 15)), int(rs.choice([12, 25, 50])), path, float(rs.choice([4.0, 6.0, 7.5, 9.0])), nm, float(rs.choice([0.3, 1.0])),
                                  int(rs.choice([nm + 3, 2 * nm])))]

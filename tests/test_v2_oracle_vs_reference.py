@@ -174,3 +174,29 @@ def test_frame_decode_gf64_with_supplied_tables(v2):
         for k in ("vtoc", "vtoci", "ctov", "ctovi", "app"):
             assert a[k].tobytes() == b[k].tobytes(), (seed, k)
     r.close()
+
+
+@pytest.mark.parametrize("name,q,nm,nop,itmax,cases", [
+    ("V2Irr_M24_GF256", 256, 20, 40, 8, ((0.55, 41), (0.8, 42), (1.1, 43))),       # irregular (2, dc): degrees 2..12, the largest in row 0
+    ("V2Irr_M24_GF256", 256, 8, 11, 5, ((0.7, 44),)),
+    ("V2Wide22_M10_GF256", 256, 20, 40, 6, ((0.4, 45), (0.6, 46))),                # dc = 22
+    ("Ahmed_64800_R910_GF256", 256, 20, 40, 3, ((0.3, 47),)),                      # the reference's rate-9/10 matrix, dc = 20
+])
+def test_frame_decode_other_check_degrees(v2, name, q, nm, nop, itmax, cases):
+    """Round 5: check degrees above 16 and irregular (2, dc) codes (v2.c:1756-1852 loops over rowDegree[node]; :750 / :794-800 size the
+    scratch by rowDegree[0]) -- the oracle against the REAL functions, all message state."""
+    if not os.path.exists(v2.REF_V2):
+        pytest.skip("oracle/_ref/libref_v2.so not built")
+    path = os.path.join(MAT, name)
+    o = v2.V2Oracle(path)
+    with quiet():
+        r = v2.RefV2(path, nm)
+    for sigma, seed in cases:
+        like, idx = v2.synthetic_likelihood(o.N, q, 8, o.o.idx2bin, sigma, seed)
+        a = o.decode(like, idx, nm, nop, 0.3, itmax)
+        with quiet():
+            b = r.decode(like, idx, nop, 0.3, itmax)
+        assert a["iters"] == b["iters"] and a["synd"] == b["synd"] and (a["decide"] == b["decide"]).all()
+        for k in ("vtoc", "vtoci", "ctov", "ctovi", "app"):
+            assert a[k].tobytes() == b[k].tobytes(), (seed, k)
+    r.close()
