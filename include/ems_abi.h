@@ -72,8 +72,9 @@ int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
  *     above 32 the literal selection and bubble loop run;
  *   - a check node may list one variable node twice (none of the reference's matrices does; nothing in it forbids it): both edges read the
  *     same APP row (NB_LDPC.c:329-337), the later edge's APP update and decision stay (:444-450); such codes run the generic kernels;
- *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), regular check degree <= 16, variable degree 2 on two different check nodes (v2.c:2157
- *     handles nothing else). */
+ *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), variable degree 2 on two different check nodes (v2.c:2157 handles nothing else); check
+ *     degree 2..64, regular or irregular as above (v2.c:1756-1852 loops over rowDegree[node], :750 / :794-800 size the scratch by
+ *     rowDegree[0]): regular degrees up to 16 on lane rows, everything else in passes (k_decode_v2_wide, round 5). */
 int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *prm, int max_batch, int device);
 void ems_destroy(ems_handle *h);
 int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */
@@ -154,7 +155,7 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf);
  * Max-is-best log-likelihoods, nm-long messages both ways, 4-candidate bubble check (v2.c:1547), horizontal
  * schedule (v2.c:2119-2253).  Same handle (ems_create: nm, NbOper, offset, NbIterMax, early_exit); the decode
  * runs iterations iter = 0..NbIterMax inclusive like the reference's loop.  Needs dv = 2 (the reference's Flag
- * trick, v2.c:2157), regular check degree <= 16, GF(64) or GF(256).
+ * trick, v2.c:2157), GF(64) or GF(256); any check degree 2..64, regular or irregular (the reference's dc = 20 matrix included).
  *   like / like_idx: [B][N][GF], per node the GF likelihoods in decreasing order and their symbols, i.e.
  *   decoder.likelihood / decoder.likelihood_index as ModelChannelAWGN leaves them (v2.c:1483-1497).
  *   Results through ems_get_results (decide, iterations executed, syndrome). */
