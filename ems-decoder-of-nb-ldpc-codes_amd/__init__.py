@@ -89,6 +89,7 @@ def lib():
         L.ems_source_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ems_source_draw.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_float]
         L.ems_source_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ems_source_draw_reference.argtypes = [C.c_void_p, C.c_ulonglong, C.c_int, C.c_float, C.POINTER(C.c_int)]
         L.ems_get_app.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_ctov.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ems_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -332,6 +333,13 @@ class Decoder:
     def source_draw(self, seed, first_frame, B, sigma):
         """Frames [first_frame, first_frame+B) generated in HBM (Philox stream `seed`), LLRs initialised."""
         _check(lib().ems_source_draw(self.h, int(seed), int(first_frame), int(B), float(sigma)))
+
+    def source_draw_reference(self, first_frame, B, sigma):
+        """Frames [first_frame, first_frame+B) of the REFERENCE's drand48 stream generated in HBM, bit for bit (ems_source_draw_reference);
+        returns how many samples the host recomputed (their float rounding was not decidable on the device)."""
+        n = C.c_int(0)
+        _check(lib().ems_source_draw_reference(self.h, int(first_frame), int(B), float(sigma), C.byref(n)))
+        return n.value
 
     def source_get(self, B):
         cw = np.zeros((B, self.code.N), np.int32)

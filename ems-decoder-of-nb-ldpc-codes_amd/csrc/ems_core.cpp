@@ -220,6 +220,11 @@ struct ems_handle {
     DevBuf<uint8_t> d_src_tcoef, d_src_rcoef, d_src_diag, d_src_sym, d_src_rhs;
     EmsSourcePlan src{};
     bool src_ready = false;
+    // ... and the reference's own drand48 stream on the device (ems_source_draw_reference)
+    DevBuf<uint64_t> d_src_base;         // [max_batch] LCG state at each frame's first draw
+    DevBuf<unsigned> d_src_flagcnt;      // [1]
+    DevBuf<uint2> d_src_flags;           // [SRC_FLAG_CAP] samples whose float rounding the device could not decide
+    DevBuf<float> d_src_patch;           // [SRC_FLAG_CAP] ... and the host's answers for them
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_llr_ev = false, have_dec_ev = false;
@@ -665,6 +670,7 @@ void ems_destroy(ems_handle *h)
     h->d_lvl_ptr.release(); h->d_lvl_cn.release(); h->d_cn_vn.release(); h->d_iters.release(); h->d_synd.release();
     for (DevBuf<int> *b : {&h->d_src_tptr, &h->d_src_tcol, &h->d_src_rptr, &h->d_src_rcol, &h->d_src_perm}) b->release();
     for (DevBuf<uint8_t> *b : {&h->d_src_tcoef, &h->d_src_rcoef, &h->d_src_diag, &h->d_src_sym, &h->d_src_rhs}) b->release();
+    h->d_src_base.release(); h->d_src_flagcnt.release(); h->d_src_flags.release(); h->d_src_patch.release();
     h->d_cw.release(); h->d_nberr.release(); h->d_cn_lh.release(); h->d_i2b.release(); h->d_b2i.release();
     h->d_ctov.release(); h->d_decide.release(); h->d_app.release(); h->d_noisy.release();
     h->d_scratch.release(); h->d_stamps.release(); h->d_att.release(); h->d_ctable.release();
@@ -1084,6 +1090,73 @@ int ems_source_draw(ems_handle *h, unsigned long long seed, unsigned long long f
     if (!h->src_ready) return fail(EMS_EINVAL, "ems_source_attach has not been called on this handle");
     if (!(sigma >= 0.f)) return fail(EMS_EINVAL, "sigma must be >= 0");
     HIP_TRY(ems_launch_source(h->src, seed, first_frame, B, sigma, h->d_cw.p, h->d_noisy.p, h->stream));
+    return ems_llr_init_dev(h, h->d_noisy.p, sigma, B);
+}
+
+// ---- the reference's drand48 stream on the device (kernels and the argument: ems_source.hip) ----
+namespace {
+constexpr unsigned SRC_FLAG_CAP = 1u << 16;
+constexpr uint64_t LCGA = 0x5DEECE66DULL, LCGC = 0xBULL, LCGM = (1ULL << 48) - 1;
+struct LcgStep { uint64_t a, c; };                                   // n draws in one go: x -> a x + c (mod 2^48)
+LcgStep lcg_step(uint64_t n)
+{
+    LcgStep r{1, 0}, b{LCGA, LCGC};
+    for (; n; n >>= 1) {
+        if (n & 1) { r.c = (b.a * r.c + b.c) & LCGM; r.a = (b.a * r.a) & LCGM; }
+        b.c = (b.a * b.c + b.c) & LCGM;
+        b.a = (b.a * b.a) & LCGM;
+    }
+    return r;
+}
+inline float lcg_draw(uint64_t &x) { x = (LCGA * x + LCGC) & LCGM; return (float)ldexp((double)x, -48); }   // (float)drand48(), tools.c:71-73
+}
+
+int ems_source_draw_reference(ems_handle *h, unsigned long long first_frame, int B, float sigma, int *recomputed)
+{
+    int r = check_batch(h, B);
+    if (r) return r;
+    if (!h->src_ready) return fail(EMS_EINVAL, "ems_source_attach has not been called on this handle");
+    if (!(sigma >= 0.f)) return fail(EMS_EINVAL, "sigma must be >= 0");
+    const uint64_t dpf = (uint64_t)h->K * h->logq + 2ULL * h->N * h->logq;          // draws per frame (NB_LDPC.c:255-261)
+    if (dpf >= (1ULL << 24)) return fail(EMS_EUNSUPPORTED, "more than 2^24 draws per frame");
+    if (!h->d_src_base.p && ((r = h->d_src_base.alloc((size_t)h->max_batch)) || (r = h->d_src_flagcnt.alloc(1)) || (r = h->d_src_flags.alloc(SRC_FLAG_CAP)) || (r = h->d_src_patch.alloc(SRC_FLAG_CAP)))) return r;
+    std::vector<uint64_t> base((size_t)B);
+    {
+        const LcgStep first = lcg_step((uint64_t)first_frame * dpf), frame = lcg_step(dpf);    // (X0 = 0: the reference never seeds drand48)
+        uint64_t x = first.c;                                                                    // first.a * 0 + first.c
+        for (int f = 0; f < B; ++f) { base[f] = x; x = (frame.a * x + frame.c) & LCGM; }
+    }
+    uint64_t pa[24], pc[24];
+    for (int i = 0; i < 24; ++i) { const LcgStep s2 = lcg_step(1ULL << i); pa[i] = s2.a; pc[i] = s2.c; }
+    HIP_TRY(hipMemcpyAsync(h->d_src_base.p, base.data(), sizeof(uint64_t) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_src_flagcnt.p, 0, sizeof(unsigned), h->stream));
+    HIP_TRY(ems_launch_source_reference(h->src, h->d_src_base.p, pa, pc, B, sigma, h->d_cw.p, h->d_noisy.p, h->d_src_flagcnt.p, h->d_src_flags.p, SRC_FLAG_CAP, h->stream));
+    unsigned nflag = 0;
+    HIP_TRY(hipMemcpyAsync(&nflag, h->d_src_flagcnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));                       // (the base states above are consumed by now too)
+    if (nflag > SRC_FLAG_CAP) return fail(EMS_EHIP, "frame source: %u undecided samples in one batch (room for %u): not the reference's stream?", nflag, SRC_FLAG_CAP);
+    if (nflag) {
+        // the samples whose rounding to float the device's libm could not decide: the reference's own expression with the host's libm
+        // (channel.c:58), from the two uniforms of exactly that sample
+        std::vector<uint2> fl(nflag);
+        HIP_TRY(hipMemcpy(fl.data(), h->d_src_flags.p, sizeof(uint2) * nflag, hipMemcpyDeviceToHost));
+        const double PI = 3.1415926536;                              /* channel.c:18 */
+        std::vector<float> vals(nflag);
+        for (unsigned i = 0; i < nflag; ++i) {
+            const uint2 &e = fl[i];
+            const unsigned f = e.x, pos = e.y >> 8, l = (e.y >> 1) & 0x7Fu, bit = e.y & 1u;
+            const LcgStep to = lcg_step((uint64_t)h->K * h->logq + 2ULL * pos * h->logq + 2ULL * l);
+            uint64_t x = (to.a * base[f] + to.c) & LCGM;
+            const float u = lcg_draw(x);
+            const float v = lcg_draw(x);
+            vals[i] = (float)((double)(1 - 2 * (int)bit) + (double)sigma * sqrt(-2.0 * log((double)u)) * cos(2.0 * PI * (double)v));
+        }
+        // one upload + one small kernel for the whole batch (about one sample per 64800-bit frame is undecided: thousands per launch)
+        HIP_TRY(hipMemcpyAsync(h->d_src_patch.p, vals.data(), sizeof(float) * nflag, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(ems_launch_source_patch(h->d_src_flags.p, h->d_src_patch.p, nflag, h->N, h->logq, h->d_noisy.p, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));                   // (vals lives on this stack frame)
+    }
+    if (recomputed) *recomputed = (int)nflag;
     return ems_llr_init_dev(h, h->d_noisy.p, sigma, B);
 }
 

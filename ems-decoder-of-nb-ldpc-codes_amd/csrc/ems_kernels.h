@@ -52,4 +52,9 @@ hipError_t ems_launch_syndrome_unit(const int *row_ptr, const int *col, const in
 hipError_t ems_launch_sort_llr(const float *app_dev, int N, int q, float *s_llr_dev, int *s_gf_dev, hipStream_t st);
 hipError_t ems_launch_source(const EmsSourcePlan &S, uint64_t seed, uint64_t first_frame, int B, float sigma, int *cw_dev,
                              float *noisy_dev, hipStream_t st);
+// the reference's drand48 stream on the device (ems_source.hip): base_dev[f] = LCG state at frame f's first draw, pow_a / pow_c = the LCG's
+// 2^i-step coefficients; samples whose float rounding the device cannot decide are listed in flags (count in flag_count, may exceed cap)
+hipError_t ems_launch_source_reference(const EmsSourcePlan &S, const uint64_t *base_dev, const uint64_t pow_a[24], const uint64_t pow_c[24], int B, float sigma,
+                                       int *cw_dev, float *noisy_dev, unsigned *flag_count_dev, void *flags_dev, unsigned flag_cap, hipStream_t st);
+hipError_t ems_launch_source_patch(const void *flags_dev, const float *vals_dev, unsigned n, int N, int logq, float *noisy_dev, hipStream_t st);
 hipError_t ems_debug_counters(unsigned long long *out8, int reset); // diagnostic builds (-DEMS_STAMPS) only

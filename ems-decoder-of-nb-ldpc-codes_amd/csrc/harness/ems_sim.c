@@ -8,9 +8,11 @@
  * GPU library -- frames are generated EMS_BATCH at a time (default: what fills the device, ems_suggest_batch) by EMS_THREADS host
  * threads (default: the cores, at most 16; 1 = the reference's own serial call sequence, same bits), decoded
  * together, and reported in frame order, truncated at the frame where the 40th erroneous frame occurs.
- * Several decoder handles (EMS_INFLIGHT, default 3) take turns so that the tail of one batch overlaps the next.  EMS_GPU_SOURCE=<seed> switches
- * the frame source to the device-side counter-based generator (ems_source_draw): no host generation at all,
- * statistical instead of bit parity with the reference's frames.
+ * Several decoder handles (EMS_INFLIGHT, default 3) take turns so that the tail of one batch overlaps the next.
+ * Frame source (round 5): by default the reference's drand48 frames are generated ON THE DEVICE, bit for bit (ems_source_draw_reference: exact
+ * 48-bit LCG with jump-ahead, the reference's encoder, Box-Muller in double with the undecidable float roundings recomputed on the host);
+ * EMS_HOST_SOURCE=1 keeps the host generator described above (same bits); EMS_GPU_SOURCE=<seed> switches to the device-side counter-based
+ * generator (ems_source_draw): statistical instead of bit parity with the reference's frames.
  *
  * EMS_DEVICES=0,1,...,7 runs ONE simulation on several GPUs of the node (run_multi below, ems_multi.h): one host thread per
  * device, batch j of the stream on device j mod D, and per round one RCCL all-reduce (ncclAllReduce, ncclInt64, ncclSum) of the
@@ -158,7 +160,9 @@ static int m_launch(void *c, int dev, int slot, long long first, int count)
     dev_ctx *d = &m->d[dev];
     int rc;
     d->first[slot] = first;
-    if (m->gpu_source) {
+    if (m->gpu_source == 2) {
+        if ((rc = ems_source_draw_reference(d->h[slot], (unsigned long long)(m->first_frame + first), count, m->sigma_dev, NULL))) goto bad;
+    } else if (m->gpu_source) {
         if ((rc = ems_source_draw(d->h[slot], m->gpu_seed, (unsigned long long)(m->first_frame + first), count, m->sigma_dev))) goto bad;
     } else {
         float sigma = 0.0f;                 /* the reference's stream from any frame on (LCG jump-ahead), frame-parallel on this device's share of the cores */
@@ -394,8 +398,11 @@ int main(int argc, char *argv[])
     /* EMS_GPU_SOURCE=<seed>: frames are generated on the GPU from the counter-based stream <seed> (ems_source_draw:
      * no host generation, no PCIe traffic) instead of the reference's drand48 stream -- statistical, not bit,
      * parity with the reference's trace. */
-    const int gpu_source = getenv("EMS_GPU_SOURCE") != NULL;
-    const unsigned long long gpu_seed = gpu_source ? strtoull(getenv("EMS_GPU_SOURCE"), NULL, 0) : 0ULL;
+    /* frame source: 2 = the reference's drand48 stream generated on the DEVICE (default since round 5: ems_source_draw_reference, bit for bit
+     * the frames of the host generator below, at a few per cent of its time); 0 = the same stream on the host cores (EMS_HOST_SOURCE=1:
+     * ems_draw_frames, or the reference's serial calls with EMS_THREADS=1); 1 = the counter-based device stream (EMS_GPU_SOURCE=<seed>) */
+    const int gpu_source = getenv("EMS_GPU_SOURCE") != NULL ? 1 : (getenv("EMS_HOST_SOURCE") && atoi(getenv("EMS_HOST_SOURCE")) ? 0 : 2);
+    const unsigned long long gpu_seed = gpu_source == 1 ? strtoull(getenv("EMS_GPU_SOURCE"), NULL, 0) : 0ULL;
     /* EMS_FIRST_FRAME=<f>: this process simulates frames [f, f + NbMonteCarlo) of the stream (0-based), e.g. one process
      * per GPU on disjoint ranges; 0 = the reference's run. */
     const long first_frame = getenv("EMS_FIRST_FRAME") ? atol(getenv("EMS_FIRST_FRAME")) : 0L;
@@ -529,7 +536,13 @@ int main(int argc, char *argv[])
                 if (!have_next) generate(n);
             }
             ems_handle *h = hd[launched % NH];                          /* asynchronous: upload, LLR kernel, decode kernel */
-            if (gpu_source) {
+            if (gpu_source == 2) {
+                struct timespec g0, g1;
+                clock_gettime(CLOCK_MONOTONIC, &g0);
+                if ((rc = ems_source_draw_reference(h, (unsigned long long)j->first, j->B, sigma_dev, NULL))) die("ems_source_draw_reference", rc);
+                clock_gettime(CLOCK_MONOTONIC, &g1);
+                t_gen += (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);   /* (it waits for its own kernels: the host patches undecided samples) */
+            } else if (gpu_source) {
                 if ((rc = ems_source_draw(h, gpu_seed, (unsigned long long)j->first, j->B, sigma_dev))) die("ems_source_draw", rc);
             } else if ((rc = ems_llr_init(h, j->noisy, j->sigma, j->B))) die("ems_llr_init", rc);
             if ((rc = ems_decode(h, j->B))) die("ems_decode", rc);
@@ -567,7 +580,7 @@ int main(int argc, char *argv[])
     /* the reference's `nb` is one past the last frame when the loop runs to completion (NB_LDPC.c:576) */
     report(file_name, EbN, nbErroneousFrames, stop ? nb : nb + 1, total_errors, sum_it, K, logGF);
     fprintf(stderr, "[ems_sim] %d frames, simulation loop wall %.3f s (%.1f frames/s incl. PCIe and generation), batch %d; %s frame generation %.3f s on %d thread(s)\n",
-            nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, gpu_source ? "device-side (no host)" : "host", t_gen, gpu_source ? 0 : threads);
+            nb, t_decode, t_decode > 0 ? nb / t_decode : 0.0, batch, gpu_source == 2 ? "device-side drand48 stream," : (gpu_source ? "device-side (no host)" : "host"), t_gen, gpu_source ? 0 : threads);
 
     for (int i = 0; i < NH; i++) ems_destroy(hd[i]);
     for (int i = 0; i < NBUF; i++) { free(cwbuf[i]); free(nybuf[i]); }

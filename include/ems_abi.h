@@ -142,7 +142,16 @@ int ems_count_errors_resident(ems_handle *h, int B, int *nb_errors /*[B] or NULL
  * and Perm [N]. */
 int ems_source_attach(ems_handle *h, const int *matUT, const int *perm);
 int ems_source_draw(ems_handle *h, unsigned long long seed, unsigned long long first_frame, int B, float sigma);
-/* copies of what ems_source_draw produced (tests): codewords [B][N] int, noisy [B][N][logGF] float; either may be NULL */
+/* Round 5: the REFERENCE's own stream on the device -- frames [first_frame, first_frame + B) (0-based) of the drand48 sequence the
+ * reference's main() consumes (X0 = 0; per frame K logGF draws of RandomBinaryGenerator, tools.c:124-136, then 2 N logGF of the noise draw,
+ * channel.c:52-62), bit for bit what ems_draw_frames generates on the host cores: the LCG in exact 48-bit integer arithmetic with
+ * jump-ahead per frame and per thread, the encoder of ems_source_attach, the Box-Muller sample in double on the device -- and, because the
+ * device's log / cos are not the host's to the last bit, every sample whose rounding to float they could move (about one in 60 000, mostly samples near 0 where floats are dense) recomputed
+ * on the host with the reference's expression before anything reads it (*recomputed, may be NULL, receives how many).  Leaves the handle
+ * as ems_set_codewords + ems_llr_init would.  Unlike ems_source_draw it waits for its own kernels (the recomputed samples are patched in
+ * before the LLR kernel is queued). */
+int ems_source_draw_reference(ems_handle *h, unsigned long long first_frame, int B, float sigma, int *recomputed);
+/* copies of what ems_source_draw / ems_source_draw_reference produced (tests): codewords [B][N] int, noisy [B][N][logGF] float; either may be NULL */
 int ems_source_get(ems_handle *h, int B, int *codewords, float *noisy);
 
 /* ---- introspection for parity tests ---- */

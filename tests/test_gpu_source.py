@@ -223,3 +223,46 @@ def test_source_on_random_codes(pkg, refapi, osrc, orc, tmp_path, block):
         dec.close(); s.close()
         ran += 1
     assert ran >= 7, ran
+
+
+# ---- round 5: the REFERENCE's own drand48 stream generated on the device (ems_source_draw_reference) ----
+@pytest.mark.parametrize("mat,nm,first,B", [
+    ("N96_K48_GF64", 16, 0, 2048),
+    ("N96_K48_GF64", 16, 123457, 300),
+    ("Mat24_N192_M96", 16, 5, 333),
+    ("Ahmed_64800_R34_GF16", 8, 2, 130),
+    ("Ahmed_64800_R12_GF256", 20, 0, 96),
+    ("Ahmed_64800_R12_GF256", 20, 968, 70),                     # where kat_long.json L4 ends
+    ("Ahmed_64800_R910_GF256", 20, 3, 40),
+])
+def test_reference_stream_on_the_device_equals_the_host_stream(pkg, refapi, osrc, harness, mat, nm, first, B):
+    """Codewords and every noisy sample of frames [first, first + B) bit for bit against ems_draw_frames (the host generator that the
+    reference traces pin): exact 48-bit LCG with jump-ahead, the reference's float / double promotions, device-side Box-Muller in double with
+    the undecidable float roundings recomputed by the host's libm."""
+    s, so, dec = _open(pkg, refapi, osrc, mat, nm, 2 * nm, 5, B)
+    src = harness.FrameSource(os.path.join(MAT, mat), nm)
+    src.position(first)
+    cw_h, noisy_h, sigma = src.draw(B, 2.0)
+    n_host = dec.source_draw_reference(first, B, sigma)
+    cw, noisy = dec.source_get(B)
+    assert (cw == cw_h).all(), "codewords differ"
+    assert noisy.tobytes() == noisy_h.tobytes(), "noisy samples differ in %d places (host recomputed %d)" % (int((noisy.view(np.uint32) != noisy_h.view(np.uint32)).sum()), n_host)
+    assert n_host <= 16 + noisy.size // 20000                   # ~1.5e-5 of the samples are undecidable on the device (mostly samples near 0, where floats are dense)
+    src.close(); dec.close(); s.close()
+
+
+def test_reference_stream_on_the_device_feeds_the_decoder(pkg, refapi, osrc, harness):
+    """... and leaves the handle as ems_set_codewords + ems_llr_init would: the decode of device-drawn frames = the decode of the host's."""
+    mat, nm, B = "N96_K48_GF64", 16, 200
+    s, so, dec = _open(pkg, refapi, osrc, mat, nm, 32, 10, B)
+    src = harness.FrameSource(os.path.join(MAT, mat), nm)
+    src.position(40)
+    cw_h, noisy_h, sigma = src.draw(B, 2.5)
+    dec.source_draw_reference(40, B, sigma)
+    dec.decode(B)
+    d1, it1, sy1 = dec.results(B)
+    nb1 = dec.count_errors_resident(B)
+    d2, it2, sy2 = dec.decode_batch(noisy_h, sigma)
+    nb2 = dec.count_errors(cw_h)
+    assert (d1 == d2).all() and (it1 == it2).all() and (sy1 == sy2).all() and (nb1 == nb2).all() and nb1.sum() > 0
+    src.close(); dec.close(); s.close()
