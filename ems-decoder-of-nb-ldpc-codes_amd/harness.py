@@ -146,7 +146,9 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     round launched ahead of the 40-error stop is dropped, exactly like a frame drawn ahead of it.
     source="host" draws the reference's own frames (drand48 stream, bit-exact traces); source="device" lets
     the GPU generate frame f from the counter-based stream `seed` (ems_source_draw: no host work, no PCIe
-    traffic; statistical parity only) -- frame f is the same on any rank count or batch.
+    traffic; statistical parity only, SURVEY.md 8(f) f2) -- frame f is the same on any rank count or batch;
+    source="device_reference" (round 5) generates the REFERENCE's drand48 frames on the GPU, bit for bit (ems_source_draw_reference):
+    the traces of source="host" with no host generation.
     Returns (Counters on every rank -- identical everywhere --, number of decode rounds)."""
     import torch
     dist = _dist()
@@ -159,7 +161,7 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
         inflight = max(1, int(inflight))
         decs = [Decoder(code, nm, NbOper, offset, NbIterMax, max_batch=batch, device=device) for _ in range(inflight)]
 
-        if source == "device":
+        if source in ("device", "device_reference"):
             for d in decs:
                 d.source_attach(src.s)
             sigma_dev = float(np.float32(np.sqrt(1.0 / (2.0 * float(src.s.code.rate) * 10.0 ** (float(np.float32(EbN)) / 10.0)))))   # channel.c:51
@@ -176,7 +178,10 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
 
         def submit_device(slot, start, count):          # frames [start, start+count) generated and decoded in HBM
             d = decs[slot]
-            d.source_draw(seed, start, count, sigma_dev)
+            if source == "device_reference":
+                d.source_draw_reference(start, count, sigma_dev)
+            else:
+                d.source_draw(seed, start, count, sigma_dev)
             d.decode(count)
 
             def collect():
@@ -195,12 +200,13 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
     stop = False
     n_rounds = -(-NbMonteCarlo // (batch * world))
 
-    if source not in ("host", "device") or (source == "device" and not decs):
-        raise ValueError("source must be 'host' or 'device' (device needs the GPU decoder)")
+    on_device = source in ("device", "device_reference")
+    if source not in ("host", "device", "device_reference") or (on_device and not decs):
+        raise ValueError("source must be 'host', 'device' or 'device_reference' (the device sources need the GPU decoder)")
 
     def draw_round(r):                                  # this rank's frames of round r (host work)
         start, count = batch_of_rank(r, rank, world, batch, NbMonteCarlo)
-        if count <= 0 or source == "device":
+        if count <= 0 or on_device:
             return None
         src.position(start)
         return src.draw(count, EbN)
@@ -244,7 +250,7 @@ def monte_carlo(matrix, NbMonteCarlo, NbIterMax, EbN, nm, offset, NbOper, batch=
         if r + 1 < n_rounds:
             pending = pool.submit(draw_round, r + 1)
         collect = None
-        if count > 0 and source == "device":
+        if count > 0 and on_device:
             collect = submit_device(r % inflight, start, count)
         elif count > 0:
             cws, noisy, sigma = frames

@@ -266,3 +266,13 @@ def test_reference_stream_on_the_device_feeds_the_decoder(pkg, refapi, osrc, har
     nb2 = dec.count_errors(cw_h)
     assert (d1 == d2).all() and (it1 == it2).all() and (sy1 == sy2).all() and (nb1 == nb2).all() and nb1.sum() > 0
     src.close(); dec.close(); s.close()
+
+
+def test_monte_carlo_driver_with_the_reference_stream_on_the_device(pkg, harness, kat):
+    """harness.monte_carlo(source="device_reference"): the traces of the REAL executable (K2 on N = 96; K3 on the 64800-bit GF(16) code) with
+    the frames generated on the GPU."""
+    for name, batch in (("K2", 64), ("K3", 3)):
+        k = kat[name]
+        c, _ = harness.monte_carlo(os.path.join(MAT, k["matrix"].replace(".txt", "") if k["fmt"] == "kn" else k["matrix"]), k["frames"], k["NbIterMax"], k["EbN"],
+                                   k["nm"], k["offset"], k["NbOper"], batch=batch, source="device_reference")
+        assert [list(t) for t in c.trace] == [list(t) for t in k["trace"]], name
