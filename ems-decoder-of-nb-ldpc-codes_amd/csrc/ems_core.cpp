@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/ems_abi.h"
@@ -88,6 +89,49 @@ static size_t device_lds_per_cu(int device)
     return (size_t)v;
 }
 static inline size_t lds_granted(size_t bytes) { return (bytes + kLdsGrant - 1) & ~(kLdsGrant - 1); }
+
+// k_decode_wide's list buffers (EmsPlan::wide_buf).  A visit of degree d works on 4 d - 6 lists (bubble_decoder.c:166-227: inputs in(t), prefixes
+// P(k), suffixes S(k), merges M(k); ids as kernels/ems_cn.inc: list_P / list_S / list_M) but never on all of them at once: in(t) is read by the
+// forward step t and the backward step d - 1 - t and dead behind the later one, P(k) and S(k) are dead behind their merge.  Stage by stage the
+// results take the lowest free buffer; a buffer is free for stage t once every reader of its list ran in a stage BEFORE t (a stage's tasks run
+// side by side, so a result may not take the buffer of an operand of the same stage).  Inputs keep buffers 0..d-1, the d output lists (S(1), M(k),
+// P(d-2)) stay to the end.  Returns the number of buffers; buf[id] = buffer of list id.
+static int wide_buffer_plan(int d, uint8_t *buf /*[256]*/)
+{
+    memset(buf, 0, 256);
+    if (d < 2) return 0;
+    auto Pl = [&](int k) { return k == 0 ? 0 : d + (k - 1); };
+    auto Sl = [&](int k) { return k == d - 1 ? d - 1 : d + (d - 2) + (k - 1); };
+    auto Ml = [&](int k) { return d + 2 * (d - 2) + k; };
+    const int nl = d + 3 * (d - 2), FOREVER = 1 << 30;
+    std::vector<int> last(std::max(nl, d), 0);
+    std::vector<std::vector<std::array<int, 3>>> stages;
+    for (int t = 1; t <= d - 2; ++t) {
+        std::vector<std::array<int, 3>> tk;
+        tk.push_back({Pl(t - 1), t, Pl(t)});
+        tk.push_back({Sl(d - t), d - 1 - t, Sl(d - 1 - t)});
+        for (int k = 0; k <= d - 3; ++k)
+            if (std::max(k, d - 3 - k) + 1 == t) tk.push_back({Pl(k), Sl(k + 2), Ml(k)});
+        for (auto &x : tk) { last[x[0]] = std::max(last[x[0]], t); last[x[1]] = std::max(last[x[1]], t); }
+        stages.push_back(tk);
+    }
+    for (int t = 0; t < d; ++t) last[d == 2 ? 1 - t : (t == 0 ? Sl(1) : (t == d - 1 ? Pl(d - 2) : Ml(t - 1)))] = FOREVER;   // the edges' outputs (bubble_decoder.c:231-254)
+    std::vector<int> alive, freeb;
+    for (int t = 0; t < d; ++t) { buf[t] = (uint8_t)t; alive.push_back(t); }
+    int nb = d;
+    for (int t = 1; t <= d - 2; ++t) {
+        for (size_t i = 0; i < alive.size();)
+            if (last[alive[i]] < t) { freeb.push_back(buf[alive[i]]); alive.erase(alive.begin() + (long)i); } else ++i;
+        std::sort(freeb.begin(), freeb.end());
+        for (auto &x : stages[(size_t)t - 1]) {
+            int b;
+            if (!freeb.empty()) { b = freeb.front(); freeb.erase(freeb.begin()); } else b = nb++;
+            buf[x[2]] = (uint8_t)b;
+            alive.push_back(x[2]);
+        }
+    }
+    return nb;
+}
 
 struct CnSchedule {
     int nsteps = 0, n_lists = 0;
@@ -188,6 +232,8 @@ struct ems_handle {
     ems_params prm{};
     std::vector<int> lvl_ptr, lvl_cn, cn_vn, t_vn, t_lh, t_pred, t_cnp, iso_vn;
     bool wide = false;                   // largest check degree above 16: k_decode_wide
+    int wide_nbuf = 0;                   // ... its list buffers per wave (wide_buffer_plan over the code's degrees)
+    DevBuf<uint8_t> d_wide_buf;          // [EMS_MAX_DC + 1][256]
     bool regular = true;                 // every check node has degree dc (and no check node lists a variable node twice); else dc = the largest degree and the tables below are used
     long repeats = 0;                    // edges that repeat a variable node of their own check node
     std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
@@ -236,7 +282,7 @@ struct ems_handle {
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
     bool q16t_overlap = false;          // EMS_Q16T_OVERLAP=1 (create time): no barrier between the sweeps of a fixed-work run of that kernel
-    bool wide_dc9 = false;              // EMS_WIDE=1 (create time): GF(256) codes with check degree 9..16 on k_decode_wide
+    int wide_pref = 1;                  // EMS_WIDE (create time, A/B runs): 0 = k_decode_wide only above degree 16; 1 (default) = also GF(256) codes with check degree 9..16 or irregular degrees; 2 = every GF(256) code
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
     std::string last_kernel;            // what the last ems_decode / ems_v2_decode launched
@@ -431,10 +477,11 @@ int refresh_plan(ems_handle *h)
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
     P.rec_bytes = ems_rec_bytes(h->nm_alloc);
     P.wide = h->wide ? 1 : 0;
-    P.wave_lds_bytes = h->wide ? (int)ems_wide_wave_lds_bytes(h->q, h->dc, p.nm) : (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
+    P.wide_buf = h->d_wide_buf.p; P.wide_nbuf = h->wide_nbuf;
+    P.wave_lds_bytes = h->wide ? (int)ems_wide_wave_lds_bytes(h->q, h->dc, p.nm, h->wide_nbuf) : (int)ems_wave_lds_bytes(h->q, h->dc, p.nm, h->cs.n_lists);
     int widest = 1;
     for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-    const int wcap = h->wide ? 8 : ems_max_waves_for(h->dc, h->q);
+    const int wcap = h->wide ? ems_wide_max_waves(h->q) : ems_max_waves_for(h->dc, h->q);
     int waves = std::min(wcap, widest);
     if (h->tune.waves > 0) waves = std::max(1, std::min(wcap, h->tune.waves));                  // ems_set_tuning
     const size_t lds_cap = h->lds_cu;
@@ -680,7 +727,7 @@ void ems_destroy(ems_handle *h)
     h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
     h->d_g_cn.release(); h->d_g_vn.release(); h->d_g_lh.release(); h->d_g_pred.release();
-    h->d_fail.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
+    h->d_fail.release(); h->d_wide_buf.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -709,7 +756,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->pair_order = env_int("EMS_PAIR_ORDER", 1);
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
-        h->wide_dc9 = env_int("EMS_WIDE", 0) != 0;
+        h->wide_pref = env_int("EMS_WIDE", 1);
         h->q16t_overlap = env_int("EMS_Q16T_OVERLAP", 0) != 0;
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
@@ -738,9 +785,11 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     // Up to 16 edges a check node's edges each own a row of the wavefront's lanes; above that (the reference's Ahmed_64800_R910_GF256 has
     // dc = 20, and it caps the degree nowhere: init.c:320, bubble_decoder.c:166-227) k_decode_wide walks them in passes.
     if (h->dc > EMS_MAX_DC) return bail(fail(EMS_EUNSUPPORTED, "check degree %d: degrees up to %d are built", h->dc, EMS_MAX_DC));
-    // (dc 9..16 over GF(256): rows of 4 lanes keep 64 symbols per lane -- 256 VGPRs and spills; EMS_WIDE=1 / the default below sends those
-    //  codes through the pass-walking kernel too, rows of 8 lanes in two passes)
-    h->wide = h->dc > 16 || (h->dc > 8 && h->q == 256 && h->wide_dc9);
+    // GF(256) beyond the lane-row kernels' best shapes (round 5): check degrees 9..16 (rows of 4 lanes keep 64 symbols per lane: 256 VGPRs and
+    // spills) and irregular degrees (the generic rows-of-8 kernel: 168 VGPRs + 45 spilled dwords) run the pass-walking kernel too -- rows of 16
+    // lanes, twelve waves per CU, recycled list buffers.  Measured at batch 256, fixed work, same box: dc = 10 (Ahmed_64800_R45_GF256) 892 ->
+    // 1564 frames/s, dc = 12 (R56) 1187 -> 1612, degrees 3 / 4 / 5 (Irr345) 1670 -> 1745; dc = 8 (R34) stays on k_decode<256, 8, 8, 20>: 2266 against 1718.
+    h->wide = h->dc > 16 || (h->q == 256 && h->wide_pref >= 1 && (h->dc > 8 || !h->regular)) || (h->q == 256 && h->wide_pref >= 2);
     if (!h->wide && h->q < ems_lpe_for(h->dc)) return bail(fail(EMS_EUNSUPPORTED, "GF(%d) with check degree %d is not built", h->q, h->dc));
     if ((r = build_cn_schedule(h->dc, h->cs))) return bail(r);
 
@@ -752,6 +801,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     // a check node that lists a variable node twice: the generic one-visit kernels (per-row "keeps its APP row to itself" flag in t_lh), as
     // for irregular degrees
     if (h->repeats) h->regular = false;
+    if (!h->regular && h->q == 256 && h->wide_pref >= 1) h->wide = true;   // (see the rule above: irregular GF(256) codes on the pass-walking kernel)
     {   // Hard decisions are written by the check-node visits; a variable node outside every check (column degree 0)
         // keeps its channel APP for the whole decode, so Decision (tools.c:312) gives the same symbol every sweep: it is
         // decided once, right after the LLR init (k_decide_rows).
@@ -761,6 +811,16 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
             if (!touched[n]) h->iso_vn.push_back(n);
     }
     build_tasks(h, c);
+    if (h->wide) {                                             // list buffers of k_decode_wide, per check degree present in the code
+        std::vector<uint8_t> tb((size_t)(EMS_MAX_DC + 1) * 256, 0);
+        h->wide_nbuf = h->dc;
+        for (int m = 0; m < c->M; ++m) {
+            const int d = c->rowDegree[m];
+            if (d < 2 || d > EMS_MAX_DC) return bail(fail(EMS_EUNSUPPORTED, "check node %d has degree %d (2..%d)", m, d, EMS_MAX_DC));
+            if (tb[(size_t)d * 256 + 1] == 0) h->wide_nbuf = std::max(h->wide_nbuf, wide_buffer_plan(d, &tb[(size_t)d * 256]));   // (buf[1] = 1 once planned)
+        }
+        if ((r = h->d_wide_buf.upload(tb))) return bail(r);
+    }
     if (h->regular && (h->dc == 4 || h->dc == 8)) build_pairs(h);
     if (h->regular && h->dc == 8 && h->q == 16) build_groups(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(EMS_EHIP, "hipStreamCreate failed"));

@@ -13,8 +13,9 @@ size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 bool ems_has_q16t_kernel(const EmsPlan &P);                 // GF(16) dc 8 nm 8 in lane-serial form (k_decode_q16t)
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves);
 int ems_q16t_max_waves();
+int ems_wide_max_waves(int q);                                 // waves per workgroup k_decode_wide is built for
 int ems_wide_lpe(int q);                                     // lanes per edge row of k_decode_wide (check degree above 16)
-size_t ems_wide_wave_lds_bytes(int q, int dc, int nm);
+size_t ems_wide_wave_lds_bytes(int q, int dc, int nm, int nbuf);   // nbuf: list buffers per wave (EmsPlan::wide_nbuf)
 bool ems_has_occ4_kernel(const EmsPlan &P);
 bool ems_has_dual_kernel(const EmsPlan &P);                  // two check-node visits per wave (GF(256) dc 4 nm 20; GF(16) dc 8 nm 8)
 size_t ems_v2wide_wave_lds_bytes(int q, int dc, int nm);      // one wave of k_decode_v2_wide (the v2 flavour on any check degree; P.t_dc set)

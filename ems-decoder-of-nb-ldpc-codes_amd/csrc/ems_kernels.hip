@@ -169,7 +169,8 @@ static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
 }
 // check degree above 16 (k_decode_wide)
 int ems_wide_lpe(int q) { return wide_lpe(q); }
-size_t ems_wide_wave_lds_bytes(int q, int dc, int nm) { return (size_t)wide_wave_bytes(q, dc, nm); }
+int ems_wide_max_waves(int q) { return wide_max_waves(q); }
+size_t ems_wide_wave_lds_bytes(int q, int dc, int nm, int nbuf) { return (size_t)wide_wave_bytes(q, dc, nm, nbuf); }
 template <int Q, int LPE> static hipError_t launch_decode_wide_t(const EmsPlan &P, int B, hipStream_t st)
 {
     g_kname = kname_fmt("k_decode_wide<%d, %d>", Q, LPE);
@@ -197,9 +198,10 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
         return launch_decode_q16t(P, B, st);
     }
     if (P.wide) {
-        if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > 8 || P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm))
+        if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > wide_max_waves(P.q) || !P.wide_buf || P.wide_nbuf < P.dc ||
+            P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm, P.wide_nbuf))
             return hipErrorInvalidValue;
-        if (P.q == 256) return launch_decode_wide_t<256, 8>(P, B, st);
+        if (P.q == 256) return launch_decode_wide_t<256, EMS_WIDE_LPE256>(P, B, st);
         if (P.q == 64) return launch_decode_wide_t<64, 4>(P, B, st);
         if (P.q == 16) return launch_decode_wide_t<16, 4>(P, B, st);
         return hipErrorInvalidValue;

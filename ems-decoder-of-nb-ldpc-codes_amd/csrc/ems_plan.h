@@ -85,6 +85,10 @@ struct EmsPlan {
     const int *q_pred;      // [n_groups*128] the previous visitor of that variable node: (group << 1) | 1 = an earlier group of this sweep,
                             //                (group << 1) | 0 = none in this sweep: the node's LAST visitor of the sweep before; -1 = empty slot
     int wide;               // launch k_decode_wide (check degree above 16: the edges of a visit in passes; t_dc / t_e0 always set)
+    // k_decode_wide keeps the 4 dc - 6 lists of a visit (inputs, prefixes, suffixes, merges: bubble_decoder.c:166-227) in FEWER buffers: a result
+    // takes the buffer of a list whose last reader is an EARLIER stage (host: wide_buffer_plan; dc = 20: 42 buffers for 74 lists).
+    const uint8_t *wide_buf;  // [EMS_MAX_DC + 1][256] buffer of list id, per check degree
+    int wide_nbuf;            // buffers the wave's list area holds (the largest need among the code's degrees)
     int twin;               // launch k_decode_twin: one wave per PAIR OF FRAMES, check nodes in reference order (tiny codes)
     const int *p_cn;        // [n_pairs*2] check node (bits 0..23) | SIMD priority of the pair (24..25) | bit 30: no second member (entry repeats the first)
     const int *p_vn;        // [n_pairs*2dc] variable nodes, row = member * dc + edge
