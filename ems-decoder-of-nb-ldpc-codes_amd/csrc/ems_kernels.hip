@@ -24,6 +24,7 @@
 // tie-breaks (lowest symbol / lowest competitor) and the 1e5 sentinel comparisons as in the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ems_kernels.h"
 
@@ -130,7 +131,8 @@ size_t ems_dual_wg_lds_bytes(int q, int dc, int nm, int n_pairs, int waves) { re
 template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const EmsPlan &P, int B, hipStream_t st)
 {
     g_kname = kname_fmt("k_decode_dual<%d, %d, %d>", Q, NM, DC);
-    const size_t lds = ems_dual_wg_lds_bytes(Q, DC, P.nm, P.n_pairs, P.waves_per_wg);
+    static const size_t pad = getenv("EMS_LDS_PAD") ? (size_t)atoi(getenv("EMS_LDS_PAD")) : 0;   // developer knob: unused LDS per workgroup = fewer workgroups per CU (occupancy A/B, profiles/NOTES.md round 5)
+    const size_t lds = ems_dual_wg_lds_bytes(Q, DC, P.nm, P.n_pairs, P.waves_per_wg) + pad;
     hipError_t e = set_max_lds(k_decode_dual<Q, NM, DC>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_decode_dual<Q, NM, DC>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
