@@ -173,13 +173,13 @@ static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
 int ems_wide_lpe(int q) { return wide_lpe(q); }
 int ems_wide_max_waves(int q) { return wide_max_waves(q); }
 size_t ems_wide_wave_lds_bytes(int q, int dc, int nm, int nbuf) { return (size_t)wide_wave_bytes(q, dc, nm, nbuf); }
-template <int Q, int LPE> static hipError_t launch_decode_wide_t(const EmsPlan &P, int B, hipStream_t st)
+template <int Q, int LPE, int NM = 0> static hipError_t launch_decode_wide_t(const EmsPlan &P, int B, hipStream_t st)
 {
-    g_kname = kname_fmt("k_decode_wide<%d, %d>", Q, LPE);
+    g_kname = NM > 0 ? kname_fmt("k_decode_wide<%d, %d, %d>", Q, LPE, NM) : kname_fmt("k_decode_wide<%d, %d>", Q, LPE);
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode_wide<Q, LPE>, lds);
+    hipError_t e = set_max_lds(k_decode_wide<Q, LPE, NM>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_decode_wide<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipLaunchKernelGGL((k_decode_wide<Q, LPE, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
 // kernels that also exist in the 16-waves-per-CU build
@@ -203,6 +203,7 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
         if (P.twin || P.dual || P.occ4 || !P.t_dc || !P.t_e0 || P.waves_per_wg > wide_max_waves(P.q) || !P.wide_buf || P.wide_nbuf < P.dc ||
             P.wave_lds_bytes != (int)ems_wide_wave_lds_bytes(P.q, P.dc, P.nm, P.wide_nbuf))
             return hipErrorInvalidValue;
+        if (P.q == 256 && P.nm == 20 && spec_ok(P)) return launch_decode_wide_t<256, EMS_WIDE_LPE256, 20>(P, B, st);   // the reference's GF(256) message size, compile-time
         if (P.q == 256) return launch_decode_wide_t<256, EMS_WIDE_LPE256>(P, B, st);
         if (P.q == 64) return launch_decode_wide_t<64, 4>(P, B, st);
         if (P.q == 16) return launch_decode_wide_t<16, 4>(P, B, st);
