@@ -238,6 +238,8 @@ struct ems_handle {
     long repeats = 0;                    // edges that repeat a variable node of their own check node
     std::vector<int> row_ptr, t_dc, t_e0;   // first edge of every check node [M+1]; per task (level order): its degree, its first edge
     DevBuf<int> d_row_ptr, d_t_dc, d_t_e0;
+    std::vector<unsigned> p_pack;        // k_decode_pair16's packed (variable node | coefficient | predecessor) word per (pair, visit, edge); empty when the code does not fit it
+    DevBuf<unsigned> d_p_pack;
     std::vector<int> p_cn, p_vn, p_lh, p_pred, p_task;   // check nodes in pairs (k_decode_dual), see build_pairs; p_task: task index per (pair, member), -1 = none
     std::vector<int> g_cn, g_vn, g_lh, g_pred;   // check nodes in groups of 16 (k_decode_q16t), see build_groups
     int n_groups = 0;
@@ -282,6 +284,7 @@ struct ems_handle {
     bool q16t_ok = true;                // EMS_Q16T=0 (create time): never the lane-serial GF(16) kernel (A/B runs)
     int q16t_waves = 0;                 // EMS_Q16T_WAVES=<n> (create time): its workgroup size (A/B runs)
     bool q16t_overlap = false;          // EMS_Q16T_OVERLAP=1 (create time): no barrier between the sweeps of a fixed-work run of that kernel
+    int pair16_pref = 0;                // EMS_PAIR16 (create time): 0 = never (default), 1 = k_decode_pair16 from seven frames per CU on, 2 = from five on (A/B runs)
     int wide_pref = 1;                  // EMS_WIDE (create time, A/B runs): 0 = k_decode_wide only above degree 16; 1 (default) = also GF(256) codes with check degree 9..16 or irregular degrees; 2 = every GF(256) code
     DevBuf<int> d_fail;                 // sticky "a dependency wait gave up" word, set by the decode kernels
     int *fail_host = nullptr;           // pinned landing slot of its copy
@@ -412,6 +415,14 @@ void build_pairs(ems_handle *h)
             }
         }
     }
+    // k_decode_pair16 reads ONE word per (pair, visit, edge) -- it lives on 128 VGPRs and prefetches the next pair's descriptors under the
+    // current one: variable node (13 bits) | log of the coefficient (8) | pair of the previous visitor + 1 (11)
+    h->p_pack.clear();
+    if (dc == 4 && h->N <= (1 << 13) && NP < (1 << 11) - 1 && h->q <= 256) {
+        h->p_pack.resize((size_t)NP * R);
+        for (size_t i = 0; i < h->p_pack.size(); ++i)
+            h->p_pack[i] = (unsigned)h->p_vn[i] | ((unsigned)(h->p_lh[i] & 0xFF) << 13) | ((unsigned)(h->p_pred[i] + 1) << 21);
+    }
 }
 
 // Groups for the lane-serial GF(16) kernel (k_decode_q16t): up to 16 check nodes per group, mutually independent, every predecessor of a
@@ -468,10 +479,10 @@ int refresh_plan(ems_handle *h)
     P.lvl_ptr = h->d_lvl_ptr.p; P.lvl_cn = h->d_lvl_cn.p; P.cn_vn = h->d_cn_vn.p; P.cn_lh = h->d_cn_lh.p;
     P.nsteps = h->cs.nsteps; P.n_lists = h->cs.n_lists;
     P.t_cn = h->d_t_cnp.p; P.t_vn = h->d_t_vn.p; P.t_lh = h->d_t_lh.p; P.t_pred = h->d_t_pred.p;
-    P.n_pairs = h->n_pairs; P.dual = 0;
+    P.n_pairs = h->n_pairs; P.dual = 0; P.pair16 = 0;
     P.q16t = 0; P.n_groups = h->n_groups; P.q16t_overlap = h->q16t_overlap ? 1 : 0;
     P.q_cn = h->d_g_cn.p; P.q_vn = h->d_g_vn.p; P.q_lh = h->d_g_lh.p; P.q_pred = h->d_g_pred.p;
-    P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p;
+    P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p; P.p_pack = h->p_pack.empty() ? nullptr : h->d_p_pack.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
     P.app = h->d_app.p; P.ctov = h->d_ctov.p; P.decide = h->d_decide.p; P.iters = h->d_iters.p; P.synd = h->d_synd.p;
@@ -725,7 +736,7 @@ void ems_destroy(ems_handle *h)
     h->d_v2_t_dst.release(); h->d_v2_t_last.release(); h->d_v2_vn_edge.release(); h->d_v2_stage_idx.release(); h->d_v2_bad.release(); h->d_v2_like.release();
     h->d_v2_msg.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
-    h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release();
+    h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release(); h->d_p_pack.release();
     h->d_g_cn.release(); h->d_g_vn.release(); h->d_g_lh.release(); h->d_g_pred.release();
     h->d_fail.release(); h->d_wide_buf.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
@@ -757,6 +768,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
         h->wide_pref = env_int("EMS_WIDE", 1);
+        h->pair16_pref = env_int("EMS_PAIR16", 0);
         h->q16t_overlap = env_int("EMS_Q16T_OVERLAP", 0) != 0;
     }
     h->N = c->N; h->M = c->M; h->K = c->N - c->M; h->q = c->GF; h->logq = ilog2(c->GF); h->E = c->nbBranch;
@@ -830,7 +842,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
     if ((r = h->d_lvl_ptr.upload(h->lvl_ptr)) || (r = h->d_lvl_cn.upload(h->lvl_cn)) || (r = h->d_cn_vn.upload(h->cn_vn)) ||
         (r = h->d_cn_lh.upload(h->cn_lh)) || (r = h->d_i2b.upload(h->i2b)) || (r = h->d_b2i.upload(h->b2i)) ||
         (r = h->d_t_vn.upload(h->t_vn)) || (r = h->d_t_lh.upload(h->t_lh)) || (r = h->d_t_pred.upload(h->t_pred)) || (r = h->d_t_cnp.upload(h->t_cnp)) || (r = h->d_iso_vn.upload(h->iso_vn)) || (r = h->d_p_cn.upload(h->p_cn)) || (r = h->d_p_vn.upload(h->p_vn)) ||
-        (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
+        (r = h->d_p_lh.upload(h->p_lh)) || (r = h->d_p_pred.upload(h->p_pred)) || (r = h->d_p_pack.upload(h->p_pack)) || (r = h->d_app.alloc(B * h->N * h->q)) ||
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)) ||
@@ -973,6 +985,7 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     P.dual = 0;
     P.twin = 0;
     P.q16t = 0;
+    P.pair16 = 0;
     if (!h->regular || h->wide) return;                         // irregular check degrees / degrees above 16: the generic kernels in the plan's shape
     auto go_dual = [&](int waves) {
         P.dual = 1; P.waves_per_wg = waves; P.wave_lds_bytes = (int)ems_dual_wave_lds_bytes(h->q, h->dc, P.nm);
@@ -1020,6 +1033,15 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     const size_t wg4 = ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, 4);
     const long fpc = ((long)B + h->n_cu - 1) / h->n_cu;        // frames per CU
     const ShapeRule &R = shape_rule(h->q, h->dc, P.nm);
+    // OPT-IN (EMS_PAIR16=1; round 5's structural experiment): from seven frames per CU on, the two-visit kernel whose row-wise
+    // phases run one visit at a time on rows of 16 lanes -- eight 2-wave workgroups = sixteen waves per CU.  Bit-exact and tested, but 3 % SLOWER
+    // than k_decode_dual at its own best batch (3815 frames/s at batch 2048 against 3937 at 1536: the SIMDs issue 76 % of the time instead of 67 %,
+    // and a visit costs 1041 VALU instructions instead of 878), so it is not the default.  EMS_PAIR16=2: from five frames per CU on (A/B at equal batch).
+    if (allow_dual && !no_dual && h->pair16_pref > 0 && fpc >= (h->pair16_pref > 1 ? R.dual2_from : 7) && ems_has_pair16_kernel(P) &&
+        8 * lds_granted(ems_pair16_wg_lds_bytes(h->q, P.nm, P.n_pairs, 2)) <= lds_cap) {
+        P.pair16 = 1; P.waves_per_wg = 2; P.wave_lds_bytes = (int)ems_pair16_wave_lds_bytes(h->q, P.nm);
+        return;
+    }
     // five or more frames per CU: 2-wave workgroups of the two-visits-per-wave kernel, six to a CU
     if (allow_dual && !no_dual && fpc >= R.dual2_from && ems_has_dual_kernel(P) &&
         6 * lds_granted(ems_dual_wg_lds_bytes(h->q, h->dc, P.nm, P.n_pairs, 2)) <= lds_cap) { go_dual(2); return; }   // (six workgroups of their granted size, see kLdsGrant)

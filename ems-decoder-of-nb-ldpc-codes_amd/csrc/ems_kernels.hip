@@ -72,6 +72,7 @@ __device__ unsigned long long g_dbg[8];
 #include "kernels/ems_es_q16.inc"
 #include "kernels/ems_cn.inc"
 #include "kernels/ems_decode.inc"
+#include "kernels/ems_pair16.inc"
 #include "kernels/ems_q16t_lane.h"
 #include "kernels/ems_q16t.inc"
 #include "kernels/ems_v2.inc"
@@ -136,6 +137,19 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_dual_t(const Em
     hipError_t e = set_max_lds(k_decode_dual<Q, NM, DC>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_decode_dual<Q, NM, DC>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
+// the same pairs at sixteen waves per CU (k_decode_pair16): the headline configuration
+bool ems_has_pair16_kernel(const EmsPlan &P) { return spec_ok(P) && P.n_pairs > 0 && P.p_pack != nullptr && P.q == 256 && P.dc == 4 && P.nm == 20 && P.t_dc == nullptr; }
+size_t ems_pair16_wave_lds_bytes(int q, int nm) { return (size_t)pair16_wave_bytes(q, nm); }
+size_t ems_pair16_wg_lds_bytes(int q, int nm, int n_pairs, int waves) { return (size_t)dual_header_bytes(q, 4, n_pairs) + (size_t)pair16_wave_bytes(q, nm) * waves; }
+static hipError_t launch_decode_pair16(const EmsPlan &P, int B, hipStream_t st)
+{
+    g_kname = "k_decode_pair16<256, 20>";
+    const size_t lds = ems_pair16_wg_lds_bytes(P.q, P.nm, P.n_pairs, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_pair16<256, 20>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_pair16<256, 20>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
 // two frames per wave (k_decode_twin): the tiny GF(64) dc = 4 codes at nm = 16
@@ -216,6 +230,12 @@ static hipError_t launch_decode_any(const EmsPlan &P, int B, hipStream_t st)
     if (P.twin) {
         if (!ems_has_twin_kernel(P)) return hipErrorInvalidValue;
         return launch_decode_twin_t<64, 16, 4>(P, B, st);
+    }
+    if (P.pair16) {
+        if (!ems_has_pair16_kernel(P) || P.dual || P.twin || P.occ4 || P.waves_per_wg < 1 || P.waves_per_wg > 2 ||
+            P.wave_lds_bytes != (int)ems_pair16_wave_lds_bytes(P.q, P.nm))
+            return hipErrorInvalidValue;
+        return launch_decode_pair16(P, B, st);
     }
     if (P.dual) {
         if (!ems_has_dual_kernel(P) || P.waves_per_wg > ems_dual_max_waves(P.dc) || P.wave_lds_bytes != (int)ems_dual_wave_lds_bytes(P.q, P.dc, P.nm))

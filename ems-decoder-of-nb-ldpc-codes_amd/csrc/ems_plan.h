@@ -75,6 +75,7 @@ struct EmsPlan {
     // the same check nodes in PAIRS for the two-visits-per-wave kernel (k_decode_dual; dc = 4 or 8): the members of a pair
     // share no variable node and every predecessor of either lies in an earlier pair
     int n_pairs, dual;      // dual: launch k_decode_dual (wave_lds_bytes / waves_per_wg then describe ITS workgroup)
+    int pair16;             // launch k_decode_pair16 instead: the same pairs, row-wise phases one visit at a time on rows of 16 lanes, sixteen waves per CU (round 5)
     // GF(16) / dc = 8 / nm = 8 in lane-serial form (k_decode_q16t): the check nodes in GROUPS of up to 16 mutually independent ones, group i
     // depending only on groups < i
     int q16t, n_groups;     // q16t: launch k_decode_q16t
@@ -94,6 +95,7 @@ struct EmsPlan {
     const int *p_vn;        // [n_pairs*2dc] variable nodes, row = member * dc + edge
     const int *p_lh;        // [n_pairs*2dc] log of the coefficients
     const int *p_pred;      // [n_pairs*2dc] PAIR index of the previous visitor of that variable node in this sweep, or -1
+    const unsigned *p_pack; // [n_pairs*8] (k_decode_pair16; dc = 4, N <= 8192, n_pairs <= 2046) p_vn | p_lh << 13 | (p_pred + 1) << 21; null otherwise
     int nsteps;             // dc-2 forward/backward steps
     int8_t out_list[16];    // list id holding the output for edge t
     int n_lists;
