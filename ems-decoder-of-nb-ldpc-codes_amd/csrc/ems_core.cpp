@@ -823,7 +823,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
             if (!touched[n]) h->iso_vn.push_back(n);
     }
     build_tasks(h, c);
-    if (h->wide) {                                             // list buffers of k_decode_wide, per check degree present in the code
+    if (h->wide || !h->regular) {                              // list buffers of k_decode_wide / k_decode_v2_wide, per check degree present in the code
         std::vector<uint8_t> tb((size_t)(EMS_MAX_DC + 1) * 256, 0);
         h->wide_nbuf = h->dc;
         for (int m = 0; m < c->M; ++m) {
@@ -1488,14 +1488,16 @@ int ems_v2_decode(ems_handle *h, int B)
         }
     }
     if (P.t_dc != nullptr) {
-        // irregular (2, dc) code or check degree above 16: k_decode_v2_wide (edges of a visit in passes, per-visit degrees), as many waves as
-        // the frame's widest level, the kernel's launch bound (8) and the CU's LDS allow
+        // irregular (2, dc) code or check degree above 8 over GF(256) / above 16: k_decode_v2_wide (edges of a visit in passes, per-visit degrees,
+        // recycled list buffers), as many waves as the frame's widest level, the kernel's launch bound and the CU's LDS allow
         P.dual = 0; P.occ4 = 0; P.twin = 0; P.q16t = 0;
-        P.wave_lds_bytes = (int)ems_v2wide_wave_lds_bytes(h->q, h->dc, P.nm);
+        P.wide_buf = h->d_wide_buf.p; P.wide_nbuf = h->wide_nbuf;
+        P.wave_lds_bytes = (int)ems_v2wide_wave_lds_bytes(h->q, h->dc, P.nm, h->wide_nbuf);
         int widest = 1;
         for (int l = 0; l < P.n_levels; ++l) widest = std::max(widest, h->lvl_ptr[l + 1] - h->lvl_ptr[l]);
-        int waves = std::min(8, widest);
-        if (h->tune.waves > 0) waves = std::max(1, std::min(8, h->tune.waves));
+        const int cap = ems_wide_max_waves(h->q);
+        int waves = std::min(cap, widest);
+        if (h->tune.waves > 0) waves = std::max(1, std::min(cap, h->tune.waves));
         while (waves > 1 && ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > h->lds_cu) --waves;
         if (ems_wg_lds_bytes(h->q, h->M, P.wave_lds_bytes, waves) > h->lds_cu)
             return fail(EMS_EUNSUPPORTED, "v2 flavour: check degree %d with nm = %d over GF(%d) does not fit the %zu KiB of LDS", h->dc, P.nm, h->q, h->lds_cu / 1024);

@@ -18,7 +18,7 @@ int ems_wide_lpe(int q);                                     // lanes per edge r
 size_t ems_wide_wave_lds_bytes(int q, int dc, int nm, int nbuf);   // nbuf: list buffers per wave (EmsPlan::wide_nbuf)
 bool ems_has_occ4_kernel(const EmsPlan &P);
 bool ems_has_dual_kernel(const EmsPlan &P);                  // two check-node visits per wave (GF(256) dc 4 nm 20; GF(16) dc 8 nm 8)
-size_t ems_v2wide_wave_lds_bytes(int q, int dc, int nm);      // one wave of k_decode_v2_wide (the v2 flavour on any check degree; P.t_dc set)
+size_t ems_v2wide_wave_lds_bytes(int q, int dc, int nm, int nbuf);    // one wave of k_decode_v2_wide (the v2 flavour on any check degree; P.t_dc set)
 bool ems_has_v2_dual_kernel(const EmsPlan &P);               // the v2 flavour's two-visit kernel (GF(256) dc 4 nm 20)
 bool ems_has_pair16_kernel(const EmsPlan &P);                // two visits per wave at sixteen waves per CU (GF(256) dc 4 nm 20; k_decode_pair16)
 size_t ems_pair16_wave_lds_bytes(int q, int nm);

@@ -405,23 +405,24 @@ hipError_t ems_launch_decode_v2(const EmsPlan &P0, int B, hipStream_t st, const 
     if (kname) *kname = g_kname;
     return e;
 }
-size_t ems_v2wide_wave_lds_bytes(int q, int dc, int nm) { return (size_t)v2wide_wave_bytes(q, dc, nm); }
-template <int Q, int LPE> static hipError_t launch_decode_v2_wide_t(const EmsPlan &P, int B, hipStream_t st)
+size_t ems_v2wide_wave_lds_bytes(int q, int dc, int nm, int nbuf) { return (size_t)v2wide_wave_bytes(q, dc, nm, nbuf); }
+template <int Q, int LPE, int NM = 0> static hipError_t launch_decode_v2_wide_t(const EmsPlan &P, int B, hipStream_t st)
 {
-    g_kname = kname_fmt("k_decode_v2_wide<%d, %d>", Q, LPE);
+    g_kname = NM > 0 ? kname_fmt("k_decode_v2_wide<%d, %d, %d>", Q, LPE, NM) : kname_fmt("k_decode_v2_wide<%d, %d>", Q, LPE);
     const size_t lds = ems_wg_lds_bytes(Q, P.M, P.wave_lds_bytes, P.waves_per_wg);
-    hipError_t e = set_max_lds(k_decode_v2_wide<Q, LPE>, lds);
+    hipError_t e = set_max_lds(k_decode_v2_wide<Q, LPE, NM>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_decode_v2_wide<Q, LPE>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    hipLaunchKernelGGL((k_decode_v2_wide<Q, LPE, NM>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
     return hipGetLastError();
 }
 static hipError_t launch_decode_v2_any(const EmsPlan &P0, int B, hipStream_t st)
 {
     if (P0.t_dc != nullptr) {              // per-visit degrees: irregular (2, dc) codes and check degrees above 16 (k_decode_v2_wide)
-        if (P0.dual || !P0.t_e0 || !P0.cn_ptr || P0.waves_per_wg < 1 || P0.waves_per_wg > 8 || P0.dc < 2 || P0.dc > EMS_MAX_DC ||
-            P0.wave_lds_bytes != (int)ems_v2wide_wave_lds_bytes(P0.q, P0.dc, P0.nm))
+        if (P0.dual || !P0.t_e0 || !P0.cn_ptr || !P0.wide_buf || P0.wide_nbuf < P0.dc || P0.waves_per_wg < 1 || P0.waves_per_wg > wide_max_waves(P0.q) ||
+            P0.dc < 2 || P0.dc > EMS_MAX_DC || P0.wave_lds_bytes != (int)ems_v2wide_wave_lds_bytes(P0.q, P0.dc, P0.nm, P0.wide_nbuf))
             return hipErrorInvalidValue;
-        if (P0.q == 256) return launch_decode_v2_wide_t<256, 8>(P0, B, st);
+        if (P0.q == 256 && P0.nm == 20 && P0.nbOper >= 23 && P0.nbOper <= 64) return launch_decode_v2_wide_t<256, EMS_WIDE_LPE256, 20>(P0, B, st);
+        if (P0.q == 256) return launch_decode_v2_wide_t<256, EMS_WIDE_LPE256>(P0, B, st);
         if (P0.q == 64) return launch_decode_v2_wide_t<64, 4>(P0, B, st);
         return hipErrorInvalidValue;
     }
