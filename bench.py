@@ -461,23 +461,23 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
     oper = None
     OPER_EBN = {"gf256": 2.0, "gf16": 3.0, "n96": 3.0}.get(workload, 3.0)
     if side_figures and rank == 0 and world == 1 and not a.synthetic_zero_codeword:
-        nd = min(256, B)
-        with c_stdout_to_stderr():
-            src = harness.FrameSource(matrix, nm)
-            src.position(1 << 20)                   # frames far from the ones of the timed run
-            ocw, onoisy, osigma = src.draw(nd, OPER_EBN)
-            src.close()
+        # Every frame distinct: the reference's own drand48 stream from frame 2^20 on, generated in HBM (ems_source_draw_reference, DESIGN.md
+        # 4.5b).  Rounds 2-4 tiled 256 host-drawn frames: workgroups go to the XCDs round-robin, so the period-256 pattern gave every XCD
+        # the SAME frames in every tile -- the XCD whose 32 frames need the most sweeps set the time (0.74 of the fixed-work sweep rate at
+        # 12288 frames; 0.89 with the same frames shuffled, scripts/gpu_oper.py OPER_ANALYSE=1).
         Bo = 4 * B                                  # several waves of workgroups: finished frames free their CU slots for queued ones
-        reps = -(-Bo // nd)
-        ocw = np.tile(ocw, (reps, 1))[:Bo]; onoisy = np.tile(onoisy, (reps, 1, 1))[:Bo]
         OH = 3                                      # handles (own streams) launched round-robin as harness.monte_carlo / ems_sim
         ods = []                                    # do: the tail of one launch overlaps the head of the next ones
-        for _ in range(OH):
+        with c_stdout_to_stderr():
+            src = harness.FrameSource(matrix, nm)
+        osigma = float(np.float32(np.sqrt(1.0 / (2.0 * float(src.s.code.rate) * 10.0 ** (float(np.float32(OPER_EBN)) / 10.0)))))   # channel.c:51
+        for k in range(OH):
             od = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bo, device=local, early_exit=True)
-            pkg._check(pkg.lib().ems_llr_init(od.h, pkg._ptr(onoisy), np.float32(osigma), Bo))
-            od.set_codewords(ocw)
+            od.source_attach(src.s)
+            od.source_draw_reference((1 << 20) + k * Bo, Bo, osigma)     # leaves codewords, noisy samples and LLRs resident
             od.synchronize()
             ods.append(od)
+        src.close()
 
         def olaunch(od):
             od.llr_init_dev(od.noisy_dev_ptr, osigma, Bo)
@@ -502,7 +502,8 @@ def run_decode_workload(a, pkg, harness, ge, torch, dist, rank, world, local, wo
         for k in range(OK, OK + OH):
             onb, oit = ocollect(ods[k % OH])
         odt = (time.perf_counter() - t1) / OK
-        oper = {"frames_per_s": round(Bo / odt, 1), "EbN0_dB": OPER_EBN, "batch": Bo, "distinct_frames": nd,
+        oper = {"frames_per_s": round(Bo / odt, 1), "EbN0_dB": OPER_EBN, "batch": Bo, "distinct_frames": OH * Bo,
+                "frames": "the reference's drand48 stream, frames 2^20.. (generated on the device, bit-exact)",
                 "avg_iterations": round(float(oit.mean()), 2), "frame_errors": int((onb != 0).sum()),
                 "handles": OH,
                 "note": "early exit on (NB_LDPC.c:470); reported beside, never instead of, the fixed-work value"}

@@ -24,6 +24,9 @@ with bench.c_stdout_to_stderr():
 def mk(Bo):
     reps = -(-Bo // nd)
     cw = np.tile(ocw, (reps, 1))[:Bo]; no = np.tile(onoisy, (reps, 1, 1))[:Bo]
+    if os.environ.get("OPER_SHUFFLE"):                                        # break the period-256 pattern of the tiled frames
+        pm = np.random.RandomState(5).permutation(Bo)
+        cw = np.ascontiguousarray(cw[pm]); no = np.ascontiguousarray(no[pm])
     od = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bo, device=0, early_exit=True)
     pkg._check(pkg.lib().ems_llr_init(od.h, pkg._ptr(no), np.float32(osigma), Bo))
     od.set_codewords(cw)
@@ -42,6 +45,37 @@ def collect(od, Bo):
     pkg._check(pkg.lib().ems_get_results(od.h, Bo, None, pkg._ptr(it), pkg._ptr(sy)))
     return nb, it
 
+
+if os.environ.get("OPER_ANALYSE"):
+    # where the early-exit mode loses against the fixed-work sweep rate: kernel time of one launch against (sum of the frames' sweeps) / (sweeps/s)
+    Bf = 1536
+    fd = pkg.Decoder(code, nm, nop, off, itmax, max_batch=Bf, device=0, early_exit=False)
+    no = np.tile(onoisy, (Bf // nd, 1, 1))
+    for _ in range(2):
+        fd.llr_init(no, osigma); fd.decode(Bf); fd.synchronize()
+    rate = Bf * (itmax - 1) / (fd.last_decode_ms * 1e-3)
+    print("fixed work: %s %.1f ms per %d frames x %d sweeps = %.4g frame-sweeps/s" % (fd.last_kernel, fd.last_decode_ms, Bf, itmax - 1, rate), flush=True)
+    fd.close()
+    prev = None
+    for im in (3, 6, 9, 12, 16, 21, 30):                                  # marginal cost of a sweep by its index (fixed work, same frames)
+        fd = pkg.Decoder(code, nm, nop, off, im, max_batch=Bf, device=0, early_exit=False)
+        for _ in range(2):
+            fd.llr_init(no, osigma); fd.decode(Bf); fd.synchronize()
+        ms = fd.last_decode_ms
+        print("fixed work NbIterMax %2d: %.1f ms%s" % (im, ms, "" if prev is None else "  -> %.2f ms per sweep over sweeps %d..%d" % ((ms - prev[1]) / (im - prev[0]), prev[0], im - 1)), flush=True)
+        prev = (im, ms)
+        fd.close()
+    for Bo in (1536, 3072, 6144, 12288):
+        od = mk(Bo)
+        for _ in range(2):
+            launch(od, Bo); nb, it = collect(od, Bo)
+        ms = od.last_decode_ms
+        print("early exit B=%5d: %s x %d waves kernel %.1f ms = %.1f frames/s; sum of sweeps %d -> ideal %.1f ms (%.3f); avg it %.2f, max %d" %
+              (Bo, od.last_kernel, od.last_workgroup_waves, ms, Bo / ms * 1e3, it.sum(), it.sum() / rate * 1e3, it.sum() / rate * 1e3 / ms, it.mean(), it.max()), flush=True)
+        cls = np.array([it[x::8].sum() for x in range(8)], float)
+        print("      sweeps of the frames = x mod 8 (one XCD each, if workgroups go round-robin): max / mean = %.3f  %s" % (cls.max() / cls.mean(), cls.astype(int).tolist()), flush=True)
+        od.close()
+    sys.exit(0)
 
 for Bo in [int(x) for x in os.environ.get("OPER_B", "1024,2048,4096,8192").split(",")]:
     od = mk(Bo)
