@@ -74,7 +74,7 @@ int ems_gf_tables(int q, uint8_t *idx2bin /*[q]*/, uint8_t *bin2idx /*[q]*/);
  *     same APP row (NB_LDPC.c:329-337), the later edge's APP update and decision stay (:444-450); such codes run the generic kernels;
  *   - the v2 flavour (ems_v2_*): GF(64) / GF(256), variable degree 2 on two different check nodes (v2.c:2157 handles nothing else); check
  *     degree 2..64, regular or irregular as above (v2.c:1756-1852 loops over rowDegree[node], :750 / :794-800 size the scratch by
- *     rowDegree[0]): regular degrees up to 16 on lane rows, everything else in passes (k_decode_v2_wide, round 5). */
+ *     rowDegree[0]): regular degrees up to 16 (GF(256): up to 8) on lane rows, everything else in passes (k_decode_v2_wide, round 5). */
 int ems_create(ems_handle **out, const ems_code_desc *code, const ems_params *prm, int max_batch, int device);
 void ems_destroy(ems_handle *h);
 int ems_set_params(ems_handle *h, const ems_params *prm); /* nm may not exceed the value given at create */
