@@ -244,6 +244,14 @@ struct ems_handle {
     std::vector<int> g_cn, g_vn, g_lh, g_pred;   // check nodes in groups of 16 (k_decode_q16t), see build_groups
     int n_groups = 0;
     DevBuf<int> d_g_cn, d_g_vn, d_g_lh, d_g_pred;
+    // k_decode_q16t's travelling layout (EmsPlan::q_trav; kernels/ems_q16t.inc): per edge slot of the groups the packed word, the lines and the
+    // redo staging (allocated by the first decode that uses them), and whether the state of the last decode still sits there
+    std::vector<unsigned> g_vo;
+    DevBuf<unsigned> d_g_vo;
+    DevBuf<uint8_t> d_trav, d_q16t_scr;
+    bool trav_ok = false, trav_live = false;
+    int trav_B = 0;
+    bool trav_pref = false;             // EMS_Q16T_TRAV=1 (create time): k_decode_q16t on its travelling layout -- OPT-IN: 16 % fewer HBM bytes (1.57 -> 1.32 x algorithmic), 3.7 % slower (profiles/NOTES.md round 5)
     std::vector<int> v2_p_dst, v2_p_last;
     int n_pairs = 0;   // iso_vn: variable nodes no check node touches
     std::vector<uint8_t> cn_lh, i2b, b2i;
@@ -463,6 +471,36 @@ void build_groups(ems_handle *h)
             h->g_pred[dst] = h->t_pred[src] >= 0 ? (group_of[h->t_pred[src]] << 1) | 1 : (last_group[h->t_vn[src]] << 1);
         }
     }
+    // the travelling layout: every variable node on exactly two edges (of different check nodes: the code is regular, no repeats), 14 bits of node
+    // and 15 bits of edge in the packed word
+    h->g_vo.assign((size_t)NG * G * dc, 0u);
+    h->trav_ok = dc == 8 && h->N <= (1 << 14) && h->E <= (1 << 15) && h->E == 2 * h->N;
+    if (h->trav_ok) {
+        std::vector<int> ea(h->N, -1), eb(h->N, -1), ga(h->N, 0), gb(h->N, 0);          // a node's two edges and the groups that visit them
+        for (int g = 0; g < NG && h->trav_ok; ++g)
+            for (int sl = 0; sl < G; ++sl) {
+                const int cn = h->g_cn[(size_t)g * G + sl];
+                if (cn < 0) continue;
+                for (int k = 0; k < dc; ++k) {
+                    const int v = h->g_vn[((size_t)g * G + sl) * dc + k], e = cn * dc + k;
+                    if (ea[v] < 0) { ea[v] = e; ga[v] = g; }
+                    else if (eb[v] < 0) { eb[v] = e; gb[v] = g; }
+                    else h->trav_ok = false;
+                }
+            }
+        for (int v = 0; v < h->N && h->trav_ok; ++v) h->trav_ok = ea[v] >= 0 && eb[v] >= 0 && ga[v] != gb[v];
+        for (int g = 0; g < NG && h->trav_ok; ++g)
+            for (int sl = 0; sl < G; ++sl) {
+                const int cn = h->g_cn[(size_t)g * G + sl];
+                if (cn < 0) continue;
+                for (int k = 0; k < dc; ++k) {
+                    const size_t idx = ((size_t)g * G + sl) * dc + k;
+                    const int v = h->g_vn[idx], e = cn * dc + k, other = ea[v] == e ? eb[v] : ea[v];
+                    const bool first = ea[v] == e ? ga[v] < gb[v] : gb[v] < ga[v];       // groups are claimed in order: the lower group visits first
+                    h->g_vo[idx] = (unsigned)v | ((unsigned)other << 14) | (first ? 1u << 29 : 0u);
+                }
+            }
+    }
 }
 
 int refresh_plan(ems_handle *h)
@@ -482,6 +520,7 @@ int refresh_plan(ems_handle *h)
     P.n_pairs = h->n_pairs; P.dual = 0; P.pair16 = 0;
     P.q16t = 0; P.n_groups = h->n_groups; P.q16t_overlap = h->q16t_overlap ? 1 : 0;
     P.q_cn = h->d_g_cn.p; P.q_vn = h->d_g_vn.p; P.q_lh = h->d_g_lh.p; P.q_pred = h->d_g_pred.p;
+    P.q16t_trav = 0; P.q_vo = h->d_g_vo.p; P.q_trav = h->d_trav.p; P.q_scr = h->d_q16t_scr.p;
     P.p_cn = h->d_p_cn.p; P.p_vn = h->d_p_vn.p; P.p_lh = h->d_p_lh.p; P.p_pred = h->d_p_pred.p; P.p_pack = h->p_pack.empty() ? nullptr : h->d_p_pack.p;
     memcpy(P.out_list, h->cs.out_list, sizeof P.out_list);
     P.idx2bin = h->d_i2b.p; P.bin2idx = h->d_b2i.p;
@@ -737,7 +776,7 @@ void ems_destroy(ems_handle *h)
     h->d_v2_msg.release(); h->d_v2_app.release(); h->d_v2_stage_like.release();
     h->d_t_vn.release(); h->d_t_lh.release(); h->d_t_pred.release(); h->d_t_cnp.release(); h->d_iso_vn.release();
     h->d_p_cn.release(); h->d_p_vn.release(); h->d_p_lh.release(); h->d_p_pred.release(); h->d_p_pack.release();
-    h->d_g_cn.release(); h->d_g_vn.release(); h->d_g_lh.release(); h->d_g_pred.release();
+    h->d_g_cn.release(); h->d_g_vn.release(); h->d_g_lh.release(); h->d_g_pred.release(); h->d_g_vo.release(); h->d_trav.release(); h->d_q16t_scr.release();
     h->d_fail.release(); h->d_wide_buf.release(); h->d_row_ptr.release(); h->d_t_dc.release(); h->d_t_e0.release();
     if (h->fail_host) (void)hipHostFree(h->fail_host);
     for (auto &e : h->ev)
@@ -767,6 +806,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         h->pair_order = env_int("EMS_PAIR_ORDER", 1);
         h->q16t_ok = env_int("EMS_Q16T", 1) != 0;
         h->q16t_waves = env_int("EMS_Q16T_WAVES", 0);
+        h->trav_pref = env_int("EMS_Q16T_TRAV", 0) != 0;
         h->wide_pref = env_int("EMS_WIDE", 1);
         h->pair16_pref = env_int("EMS_PAIR16", 0);
         h->q16t_overlap = env_int("EMS_Q16T_OVERLAP", 0) != 0;
@@ -846,7 +886,7 @@ int ems_create(ems_handle **out, const ems_code_desc *c, const ems_params *prm, 
         (r = h->d_ctov.alloc(B * h->E * ems_rec_bytes(h->nm_alloc))) || (r = h->d_decide.alloc(B * h->N)) ||
         (r = h->d_iters.alloc(B)) || (r = h->d_synd.alloc(B)) || (r = h->d_noisy.alloc(B * h->N * h->logq)) ||
         (r = h->d_cw.alloc(B * h->N)) || (r = h->d_nberr.alloc(B)) || (r = h->d_stamps.alloc(16)) || (r = h->d_fail.alloc(1)) ||
-        (r = h->d_g_cn.upload(h->g_cn)) || (r = h->d_g_vn.upload(h->g_vn)) || (r = h->d_g_lh.upload(h->g_lh)) || (r = h->d_g_pred.upload(h->g_pred)) ||
+        (r = h->d_g_cn.upload(h->g_cn)) || (r = h->d_g_vn.upload(h->g_vn)) || (r = h->d_g_lh.upload(h->g_lh)) || (r = h->d_g_pred.upload(h->g_pred)) || (r = h->d_g_vo.upload(h->g_vo)) ||
         (r = h->d_row_ptr.upload(h->row_ptr)) || (r = h->d_t_dc.upload(h->t_dc)) || (r = h->d_t_e0.upload(h->t_e0)))
         return bail(r);
     if (hipMemset(h->d_fail.p, 0, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&h->fail_host, sizeof(int), hipHostMallocDefault) != hipSuccess)
@@ -894,6 +934,7 @@ int ems_llr_init_dev(ems_handle *h, const float *noisy_dev, float sigma, int B)
     if (!noisy_dev) return fail(EMS_EINVAL, "null noisy pointer");
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(ems_launch_llr_init(noisy_dev, sigma, h->logq, h->q, (size_t)B * h->N * h->q, h->d_i2b.p, h->d_b2i.p, h->d_app.p, h->stream));
+    h->trav_live = false;                                      // (k_decode_q16t's travelling layout: the state is the LLRs in `app` again)
     if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
@@ -935,6 +976,7 @@ int ems_llr_init_constellation(ems_handle *h, const float *obs_host, const float
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(ems_launch_llr_const(h->d_noisy.p, att_host ? h->d_att.p : nullptr, h->d_ctable.p, h->q, D, mode, sigma, (size_t)B * h->N,
                                  h->d_b2i.p, h->d_app.p, h->stream));
+    h->trav_live = false;
     if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_llr_ev = true;
@@ -947,6 +989,7 @@ int ems_load_llr(ems_handle *h, const float *llr_host, int B)
     if (r) return r;
     if (!llr_host) return fail(EMS_EINVAL, "null llr pointer");
     HIP_TRY(hipMemcpyAsync(h->d_app.p, llr_host, (size_t)B * h->N * h->q * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->trav_live = false;                                      // (k_decode_q16t's travelling layout: the state is the LLRs in `app` again)
     if (!h->iso_vn.empty()) HIP_TRY(ems_launch_decide_rows(h->d_app.p, h->d_iso_vn.p, (int)h->iso_vn.size(), B, h->N, h->q, h->d_decide.p, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return EMS_OK;
@@ -1054,15 +1097,34 @@ static void shape_for_batch(const ems_handle *h, int B, EmsPlan &P, bool allow_d
     else if (fpc >= R.wg4_from && 3 * wg4 <= lds_cap) P.waves_per_wg = 4;
 }
 
+// k_decode_q16t's travelling layout: the state of the last decode back in `app` / `ctov` (for an accessor, or a decode that continues from it)
+static int trav_export(ems_handle *h)
+{
+    if (!h->trav_live) return EMS_OK;
+    EmsPlan P = h->plan;
+    P.q_trav = h->d_trav.p;
+    HIP_TRY(ems_launch_q16t_export(P, h->trav_B, h->stream));
+    h->trav_live = false;
+    return EMS_OK;
+}
+
 int ems_decode(ems_handle *h, int B)
 {
     int r = check_batch(h, B);
     if (r) return r;
+    if ((r = trav_export(h))) return r;                          // (only when no LLR initialisation came between two decodes)
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     EmsPlan P = h->plan;
     shape_for_batch(h, B, P);
+    if (P.q16t && h->trav_ok && h->trav_pref) {                  // GF(16): one line per edge, record + travelling APP row (kernels/ems_q16t.inc)
+        if (!h->d_trav.p && ((r = h->d_trav.alloc((size_t)h->max_batch * h->E * 128)) ||
+                             (r = h->d_q16t_scr.alloc((size_t)h->max_batch * ems_q16t_max_waves() * EMS_Q16T_SCR)))) return r;
+        P.q16t_trav = 1; P.q_trav = h->d_trav.p; P.q_scr = h->d_q16t_scr.p;
+        h->plan.q_trav = h->d_trav.p; h->plan.q_scr = h->d_q16t_scr.p;
+    }
     const char *kn = "";
     HIP_TRY(ems_launch_decode(P, B, h->stream, &kn));
+    if (P.q16t_trav) { h->trav_live = true; h->trav_B = B; }
     h->last_kernel = kn;
     h->last_waves = P.waves_per_wg;
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
@@ -1269,6 +1331,7 @@ int ems_get_app(ems_handle *h, int frame, float *app)
 {
     int r = check_batch(h, frame + 1);
     if (r) return r;
+    if ((r = trav_export(h))) return r;
     if (!app || frame < 0) return fail(EMS_EINVAL, "bad argument");
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(app, h->d_app.p + (size_t)frame * h->N * h->q, sizeof(float) * (size_t)h->N * h->q, hipMemcpyDeviceToHost));
@@ -1279,6 +1342,7 @@ int ems_get_ctov(ems_handle *h, int frame, float *ctov)
 {
     int r = check_batch(h, frame + 1);
     if (r) return r;
+    if ((r = trav_export(h))) return r;
     if (!ctov || frame < 0) return fail(EMS_EINVAL, "bad argument");
     const size_t n = (size_t)h->E * h->q;
     if (h->d_scratch.n < n) {
@@ -1298,6 +1362,7 @@ int ems_get_sorted_llr(ems_handle *h, int frame, float *s_llr, int *s_gf)
 {
     int r = check_batch(h, frame + 1);
     if (r) return r;
+    if ((r = trav_export(h))) return r;
     if (!s_llr || !s_gf || frame < 0) return fail(EMS_EINVAL, "bad argument");
     const size_t n = (size_t)h->N * h->q;
     Tmp t;

@@ -13,6 +13,7 @@ size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves);
 bool ems_has_q16t_kernel(const EmsPlan &P);                 // GF(16) dc 8 nm 8 in lane-serial form (k_decode_q16t)
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves);
 int ems_q16t_max_waves();
+hipError_t ems_launch_q16t_export(const EmsPlan &P, int B, hipStream_t st);   // a decode on k_decode_q16t's travelling layout back to app / ctov
 int ems_wide_max_waves(int q);                                 // waves per workgroup k_decode_wide is built for
 int ems_wide_lpe(int q);                                     // lanes per edge row of k_decode_wide (check degree above 16)
 size_t ems_wide_wave_lds_bytes(int q, int dc, int nm, int nbuf);   // nbuf: list buffers per wave (EmsPlan::wide_nbuf)

@@ -168,19 +168,28 @@ template <int Q, int NM, int DC> static hipError_t launch_decode_twin_t(const Em
 bool ems_has_q16t_kernel(const EmsPlan &P) { return P.q == 16 && P.dc == 8 && P.nm == 8 && P.nbOper >= 1 && P.n_groups > 0 && P.q_cn != nullptr && P.t_dc == nullptr; }
 int ems_q16t_max_waves() { return EMS_Q16T_WAVES; }
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves) { return (size_t)q16t_header_bytes(n_groups) + (size_t)q16t_wave_bytes() * waves; }
+template <bool SMALL16, bool TRAV> static hipError_t launch_decode_q16t_t(const EmsPlan &P, int B, hipStream_t st)
+{
+    g_kname = TRAV ? (SMALL16 ? "k_decode_q16t<true, true>" : "k_decode_q16t<false, true>") : (SMALL16 ? "k_decode_q16t<true>" : "k_decode_q16t<false>");
+    const size_t lds = ems_q16t_wg_lds_bytes(P.n_groups, P.waves_per_wg);
+    hipError_t e = set_max_lds(k_decode_q16t<SMALL16, TRAV>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_q16t<SMALL16, TRAV>), dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    return hipGetLastError();
+}
 static hipError_t launch_decode_q16t(const EmsPlan &P, int B, hipStream_t st)
 {
-    const size_t lds = ems_q16t_wg_lds_bytes(P.n_groups, P.waves_per_wg);
-    hipError_t e;
-    if (P.nbOper == 16) {
-        g_kname = "k_decode_q16t<true>";
-        if ((e = set_max_lds(k_decode_q16t<true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_decode_q16t<true>, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
-    } else {
-        g_kname = "k_decode_q16t<false>";
-        if ((e = set_max_lds(k_decode_q16t<false>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_decode_q16t<false>, dim3(B), dim3(P.waves_per_wg * 64), lds, st, P);
+    if (P.q16t_trav) {                              // the travelling layout: its buffers and the per-edge words must be there
+        if (!P.q_vo || !P.q_trav || !P.q_scr || P.N > (1 << 14) || P.E > (1 << 15)) return hipErrorInvalidValue;
+        return P.nbOper == 16 ? launch_decode_q16t_t<true, true>(P, B, st) : launch_decode_q16t_t<false, true>(P, B, st);
     }
+    return P.nbOper == 16 ? launch_decode_q16t_t<true, false>(P, B, st) : launch_decode_q16t_t<false, false>(P, B, st);
+}
+// the state of a decode on the travelling layout back in `app` / `ctov` (k_q16t_export)
+hipError_t ems_launch_q16t_export(const EmsPlan &P, int B, hipStream_t st)
+{
+    if (!P.q_vo || !P.q_trav || !P.q_cn || P.n_groups <= 0 || B <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_q16t_export, dim3((P.n_groups * 128 + 255) / 256, B), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 // check degree above 16 (k_decode_wide)

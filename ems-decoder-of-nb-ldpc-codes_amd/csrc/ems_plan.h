@@ -31,6 +31,7 @@ struct EmsEntry {
 #ifndef EMS_REC_ALIGN
 #define EMS_REC_ALIGN 16
 #endif
+#define EMS_Q16T_SCR 1152   /* 8 APP rows | 8 records | 8 decisions | 8 row numbers, see q16t_redo_trav */
 static inline int ems_rec_bytes(int nm) { return ((5 * nm + 9) + EMS_REC_ALIGN - 1) & ~(EMS_REC_ALIGN - 1); }
 #define EMS_REC_DFLT(nm) (4 * (nm))
 #define EMS_REC_HINT(nm) (4 * (nm) + 4)
@@ -85,6 +86,13 @@ struct EmsPlan {
     const int *q_lh;        // [n_groups*128] log of its coefficient (0..14)
     const int *q_pred;      // [n_groups*128] the previous visitor of that variable node: (group << 1) | 1 = an earlier group of this sweep,
                             //                (group << 1) | 0 = none in this sweep: the node's LAST visitor of the sweep before; -1 = empty slot
+    // ... with the APP row TRAVELLING (round 5): one 128-byte line per edge in q_trav = [C->V record 64 B | APP row 64 B of the edge's variable node];
+    // a visit reads its own line (record + row: one full line) and writes the new record there and the new APP row into the line of the node's
+    // OTHER edge, which is the next to read it (variable degree 2).  The first visit of a node in sweep 0 reads the row from `app`.
+    int q16t_trav;          // launch k_decode_q16t<.., true>
+    const unsigned *q_vo;   // [n_groups*128] variable node (bits 0..13) | the node's other edge (14..28) | this edge is the node's first visit of a sweep (29)
+    uint8_t *q_trav;        // [B][E][128]
+    uint8_t *q_scr;         // [B][waves][EMS_Q16T_SCR] staging of the rare merge-form redo of one check node (process_cn on the plain layout)
     int wide;               // launch k_decode_wide (check degree above 16: the edges of a visit in passes; t_dc / t_e0 always set)
     // k_decode_wide keeps the 4 dc - 6 lists of a visit (inputs, prefixes, suffixes, merges: bubble_decoder.c:166-227) in FEWER buffers: a result
     // takes the buffer of a list whose last reader is an EARLIER stage (host: wide_buffer_plan; dc = 20: 42 buffers for 74 lists).

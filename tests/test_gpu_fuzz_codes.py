@@ -118,7 +118,7 @@ FAMILIES = [  # q, dc, nm, the knobs that force each kernel family built for thi
     (256, 4, 20, [{}, {"EMS_DUAL": "1"}, {"EMS_DUAL": "2"}, {"EMS_DUAL": "4"}, {"EMS_TWIN": "1"}, {"EMS_WAVES": "4", "EMS_OCC4": "1"}]),
     (64, 4, 16, [{}, {"EMS_DUAL": "1"}, {"EMS_DUAL": "2"}, {"EMS_TWIN": "1"}]),
     (64, 4, 24, [{}, {"EMS_DUAL": "2"}]),
-    (16, 8, 8, [{}, {"EMS_Q16T": "0"}, {"EMS_DUAL": "2"}, {"EMS_Q16T_WAVES": "3"}]),
+    (16, 8, 8, [{}, {"EMS_Q16T": "0"}, {"EMS_DUAL": "2"}, {"EMS_Q16T_WAVES": "3"}, {"EMS_Q16T_TRAV": "1"}]),
 ]
 
 
@@ -436,3 +436,53 @@ def test_more_than_255_sweeps(pkg, orc, tmp_path, monkeypatch):
             monkeypatch.delenv(k)
     print(sorted(seen))
     assert len(seen) >= 5, seen
+
+
+def test_gf16_travelling_layout_on_random_codes(pkg, orc, tmp_path, monkeypatch):
+    """k_decode_q16t on its opt-in travelling layout (EMS_Q16T_TRAV=1; kernels/ems_q16t.inc: per edge a record and a slot for the APP row of
+    its variable node, written by the node's other edge) on random (2, 8)-regular graphs over GF(16) -- who visits a node first, which
+    edge is the other one and the groups of 16 differ from code to code -- with continuous, half-integer (the merge-form redo on its
+    staging block) and partly saturated LLRs, early exit on and off: whole-frame state, through k_q16t_export, against the oracle; then
+    a second decode on the same handle without a new LLR load (the exported state is its start) against the plain layout's."""
+    monkeypatch.setenv("EMS_Q16T_TRAV", "1")
+    rs = np.random.RandomState(7700 + SEED)
+    for case in range(int(os.environ.get("EMS_FUZZ_REGULAR", "14"))):
+        path = str(tmp_path / ("trav_%d" % case))
+        N, M = _random_dv2_code(rs, path, 16, 8)
+        nop = int(rs.choice([11, 16, 16, 24]))
+        off = float(rs.choice([0.0, 0.3, 1.0]))
+        itmax = int(rs.randint(2, 8))
+        ee = bool(rs.randint(2))
+        B = int(rs.randint(3, 8))
+        llr = (rs.rand(B, N, 16) * 30).astype(np.float32)
+        llr[1] = np.round(llr[1] * 2) / 2
+        llr[2, ::3, 8:] = 1e5
+        llr -= llr.min(axis=2, keepdims=True)
+        llr[2, ::3, 8:] = 1e5
+        o = orc.Oracle(path)
+        dec = pkg.Decoder(pkg.Code(path), 8, nop, off, itmax, max_batch=B, early_exit=ee)
+        dec.load_llr(llr)
+        dec.decode(B)
+        assert dec.last_kernel.startswith("k_decode_q16t<") and dec.last_kernel.endswith(", true>"), dec.last_kernel
+        d, it, sy = dec.results(B)
+        for b in range(B):
+            ref = o.decode(llr[b], 8, nop, off, itmax, early_exit=ee, want_state=True)
+            ctx = (case, M, N, nop, off, itmax, ee, b)
+            assert (d[b] == ref["decide"]).all() and it[b] == ref["iters"] and sy[b] == ref["synd"], ctx
+            assert dec.app(b).tobytes() == ref["app"].tobytes() and dec.ctov(b).tobytes() == ref["ctov"].tobytes(), ctx
+        if case % 4 == 0:                              # decode again from the state the first decode left (APP as the new LLRs, C->V = 0)
+            dec.load_llr(llr)
+            dec.decode(B); dec.decode(B)
+            a2 = [dec.app(b).copy() for b in range(B)]
+            d2 = dec.results(B)[0].copy()
+            monkeypatch.setenv("EMS_Q16T_TRAV", "0")
+            pl = pkg.Decoder(pkg.Code(path), 8, nop, off, itmax, max_batch=B, early_exit=ee)
+            monkeypatch.setenv("EMS_Q16T_TRAV", "1")
+            pl.load_llr(llr)
+            pl.decode(B); pl.decode(B)
+            assert pl.last_kernel.endswith("<true>") or pl.last_kernel.endswith("<false>"), pl.last_kernel
+            assert (pl.results(B)[0] == d2).all(), case
+            for b in range(B):
+                assert pl.app(b).tobytes() == a2[b].tobytes(), (case, b)
+            pl.close()
+        dec.close()

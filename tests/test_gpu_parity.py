@@ -346,9 +346,12 @@ def test_decode_gf16_two_visits_per_wave_kernel_vs_oracle(pkg, orc, monkeypatch)
         _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, nop, 0.3, 5, 0.0, 1, state=True, early_exit=False)
 
 
-def test_decode_gf16_state_and_fixed_work(pkg, orc):
+@pytest.mark.parametrize("trav", ["0", "1"])
+def test_decode_gf16_state_and_fixed_work(pkg, orc, monkeypatch, trav):
     """The GF(16) configuration on its default kernel (round 4: the lane-serial k_decode_q16t; the closed forms of ems_q16t_lane.h with the
-    merge-form redo of the check nodes they do not decide): full APP / C->V state, and a non-converging fixed-work run."""
+    merge-form redo of the check nodes they do not decide): full APP / C->V state, and a non-converging fixed-work run.  Round 5: also on the
+    opt-in travelling layout (per edge a record and a slot for the APP row of its node; the state comes back through k_q16t_export)."""
+    monkeypatch.setenv("EMS_Q16T_TRAV", trav)
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 30, 3.0, 2, state=True)
     _decode_vs_oracle(pkg, orc, "Ahmed_64800_R34_GF16", 8, 16, 0.3, 6, 0.0, 2, state=True, early_exit=False)
     # NbOper = nm + 3 (the scan is cut short in one task of eight: the closed form of that cut in the 8-lane stages) and 3 nm (never)
@@ -484,7 +487,7 @@ def test_gf64_network_selection_edge_inputs(pkg, orc, monkeypatch):
         monkeypatch.delenv(knob)
 
 
-def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
+def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc, monkeypatch):
     """GF(16) / nm = 8 on the two-visits-per-wave kernel with LLRs on a coarse grid: equal first occurrences in nearly every elementary
     step, i.e. the stage leaves the first-occurrence loop and the rest of the visit runs in the merge form through the out-of-line
     call (5 wave-stages in 100 000 on the bench workload, nearly all of them here); half-integer and integer grids, full state."""
@@ -497,7 +500,13 @@ def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc):
     llr[2, ::2] = np.round(llr[2, ::2])             # every other node coarse, the rest continuous
     # the default kernel since round 4 is the lane-serial one (k_decode_q16t): on these inputs nearly every check node reports a tie its
     # 32-bit keys do not decide and is redone by the merge-form visit (q16t_redo_cn) -- the fallback under load; then the two-visit kernel
-    for forced, kernel in ((None, "k_decode_q16t<true>"), (16, "k_decode_dual<16, 8, 8>")):
+    # (round 5: also on its opt-in travelling layout, where the redo runs on a staging block: q16t_redo_trav)
+    for forced, kernel in ((None, "k_decode_q16t<true>"), ("trav", "k_decode_q16t<true, true>"), (16, "k_decode_dual<16, 8, 8>")):
+        if forced == "trav":
+            monkeypatch.setenv("EMS_Q16T_TRAV", "1")
+            forced = None
+        else:
+            monkeypatch.delenv("EMS_Q16T_TRAV", raising=False)
         dec = pkg.Decoder(pkg.Code(path), 8, 16, 0.3, 4, max_batch=3, early_exit=False)
         if forced is not None:
             dec.set_tuning(dual=forced)
