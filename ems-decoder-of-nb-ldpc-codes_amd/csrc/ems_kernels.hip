@@ -170,7 +170,7 @@ int ems_q16t_max_waves() { return EMS_Q16T_WAVES; }
 size_t ems_q16t_wg_lds_bytes(int n_groups, int waves) { return (size_t)q16t_header_bytes(n_groups) + (size_t)q16t_wave_bytes() * waves; }
 template <bool SMALL16, bool TRAV> static hipError_t launch_decode_q16t_t(const EmsPlan &P, int B, hipStream_t st)
 {
-    g_kname = TRAV ? (SMALL16 ? "k_decode_q16t<true, true>" : "k_decode_q16t<false, true>") : (SMALL16 ? "k_decode_q16t<true>" : "k_decode_q16t<false>");
+    g_kname = TRAV ? (SMALL16 ? "k_decode_q16t<true, true>" : "k_decode_q16t<false, true>") : (SMALL16 ? "k_decode_q16t<true, false>" : "k_decode_q16t<false, false>");   // (as the profiler prints them)
     const size_t lds = ems_q16t_wg_lds_bytes(P.n_groups, P.waves_per_wg);
     hipError_t e = set_max_lds(k_decode_q16t<SMALL16, TRAV>, lds);
     if (e != hipSuccess) return e;

@@ -501,7 +501,7 @@ def test_gf16_coarse_llrs_take_the_merge_form(pkg, orc, monkeypatch):
     # the default kernel since round 4 is the lane-serial one (k_decode_q16t): on these inputs nearly every check node reports a tie its
     # 32-bit keys do not decide and is redone by the merge-form visit (q16t_redo_cn) -- the fallback under load; then the two-visit kernel
     # (round 5: also on its opt-in travelling layout, where the redo runs on a staging block: q16t_redo_trav)
-    for forced, kernel in ((None, "k_decode_q16t<true>"), ("trav", "k_decode_q16t<true, true>"), (16, "k_decode_dual<16, 8, 8>")):
+    for forced, kernel in ((None, "k_decode_q16t<true, false>"), ("trav", "k_decode_q16t<true, true>"), (16, "k_decode_dual<16, 8, 8>")):
         if forced == "trav":
             monkeypatch.setenv("EMS_Q16T_TRAV", "1")
             forced = None
