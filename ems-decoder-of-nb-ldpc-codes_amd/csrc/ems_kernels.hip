@@ -93,10 +93,10 @@ size_t ems_wave_lds_bytes(int q, int dc, int nm, int n_lists)
 {
     const int lpe = ems_lpe_for(dc);
     if (!lpe) return 0;
-    const size_t dense = (size_t)(64 / lpe) * q * 4 + (size_t)(64 / lpe) * surv_stride(lpe) * 8; // staging rows + survivor scratch
-    const size_t lists = ((size_t)n_lists * list_stride(nm) * 8 + 15) & ~(size_t)15;
+    const size_t dense = (size_t)(64 / lpe) * q * 4;                     // staging rows (the elementary steps' dedupe tables alias them)
+    const size_t lists = (size_t)row_list_area_bytes(lpe, dc, nm, n_lists);   // the visit's lists, the selection's survivor scratch aliased behind the inputs
     const size_t lens = ((size_t)n_lists * 4 + 15) & ~(size_t)15;
-    return dense + lists + lens + ((ES_PICK_BYTES + 15) & ~15); // + pick bytes of the elementary steps (their dedupe tables alias the staging rows)
+    return dense + lists + lens + ((ES_PICK_BYTES + 15) & ~15); // + pick bytes of the elementary steps
 }
 
 size_t ems_wg_lds_bytes(int q, int M, size_t wave_bytes, int waves) { return (size_t)wg_header_bytes(q, M) + wave_bytes * waves; }
